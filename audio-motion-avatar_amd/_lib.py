@@ -1,0 +1,105 @@
+"""ctypes binding of libamav_hip.so (the C ABI declared in include/amav.h).
+
+There is no CPU or eager fallback: if the library is missing, or an entry point fails, an exception is raised.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libamav_hip.so")
+
+c_float_p = ctypes.c_void_p  # device pointers travel as integers (tensor.data_ptr())
+
+
+class AmavError(RuntimeError):
+    pass
+
+
+class Attr(ctypes.Structure):
+    """amav_attr: element (f, i) at ptr[f * frame_stride + i * elem_stride] (strides in floats)."""
+
+    _fields_ = [("ptr", ctypes.c_void_p), ("frame_stride", ctypes.c_int64), ("elem_stride", ctypes.c_int32),
+                ("_pad", ctypes.c_int32)]
+
+
+class RasterArgs(ctypes.Structure):
+    _fields_ = [
+        ("num_frames", ctypes.c_int32), ("num_gaussians", ctypes.c_int32), ("height", ctypes.c_int32),
+        ("width", ctypes.c_int32),
+        ("means3d", Attr), ("rotations", Attr), ("scales", Attr), ("opacities", Attr), ("colors", Attr),
+        ("viewmatrix", ctypes.c_void_p), ("projmatrix", ctypes.c_void_p), ("tanfov", ctypes.c_void_p),
+        ("bg", ctypes.c_float * 3), ("scale_modifier", ctypes.c_float),
+        ("apply_activations", ctypes.c_int32),
+        ("scale_bias", ctypes.c_float), ("scale_max", ctypes.c_float), ("opacity_bias", ctypes.c_float),
+        ("antialiasing", ctypes.c_int32), ("clamp_output", ctypes.c_int32),
+        ("out_rgba", ctypes.c_void_p), ("out_inv_depth", ctypes.c_void_p), ("out_radii", ctypes.c_void_p),
+        ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t),
+        ("instance_capacity", ctypes.c_int64),
+    ]
+
+
+class BodyTables(ctypes.Structure):
+    _fields_ = [
+        ("num_verts", ctypes.c_int32), ("num_joints", ctypes.c_int32), ("num_coeffs", ctypes.c_int32),
+        ("skin_k", ctypes.c_int32),
+        ("v_template", ctypes.c_void_p), ("blend", ctypes.c_void_p), ("j_template", ctypes.c_void_p),
+        ("j_dirs", ctypes.c_void_p), ("parents", ctypes.c_void_p), ("skin_idx", ctypes.c_void_p),
+        ("skin_w", ctypes.c_void_p),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/amav.h declares
+SIGNATURES = {
+    "amav_version": (ctypes.c_char_p, []),
+    "amav_last_error": (ctypes.c_char_p, []),
+    "amav_device_count": (ctypes.c_int, []),
+    "amav_camera_from_intrinsics": (ctypes.c_int, [ctypes.c_int, c_float_p, c_float_p, ctypes.c_int, ctypes.c_int,
+                                                   ctypes.c_float, ctypes.c_float, c_float_p, c_float_p, c_float_p,
+                                                   c_float_p, ctypes.c_void_p]),
+    "amav_rasterize_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                         ctypes.c_int64]),
+    "amav_rasterize_forward": (ctypes.c_int, [ctypes.POINTER(RasterArgs), ctypes.c_void_p]),
+    "amav_rasterize_status": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64),
+                                             ctypes.POINTER(ctypes.c_int32), ctypes.c_void_p]),
+    "amav_lbs_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.POINTER(BodyTables)]),
+    "amav_lbs_forward": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(BodyTables), c_float_p, c_float_p, c_float_p,
+                                        c_float_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "amav_points_gather": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_float_p, ctypes.c_void_p,
+                                          c_float_p, ctypes.c_void_p]),
+    "amav_triplane_project": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_float_p, ctypes.c_int64,
+                                             c_float_p, c_float_p, ctypes.c_void_p]),
+    "amav_triplane_sample_decode": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_float_p, c_float_p,
+                                                   c_float_p, ctypes.c_float, c_float_p, c_float_p,
+                                                   ctypes.c_void_p]),
+    "amav_triplane_sample_features": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                     c_float_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                                     c_float_p, ctypes.c_float, c_float_p, ctypes.c_void_p]),
+    "amav_selfattn_forward": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_float_p,
+                                             c_float_p, c_float_p, ctypes.c_int64, c_float_p, ctypes.c_int64,
+                                             ctypes.c_float, ctypes.c_void_p]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libamav_hip.so once.  Raises AmavError when it has not been built (run __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise AmavError(
+                f"{LIB_PATH} is missing: the HIP extension is the only execution path of this package "
+                "(no CPU fallback). Build it with `python -c 'import __graft_entry__ as g; g.build()'`.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError here = header and library out of sync
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().amav_last_error().decode("utf-8", "replace")
+        raise AmavError(f"{what or 'amav call'} failed ({rc}): {msg}")

@@ -1,0 +1,54 @@
+// Shared host-side helpers of libamav_hip.so (error reporting, launch checks, workspace carving).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/amav.h"
+
+namespace amav {
+
+constexpr int kWave = 64;  // gfx950 wavefront width
+
+char *error_buffer();  // thread-local, 512 bytes (api.hip)
+
+inline int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(error_buffer(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define AMAV_REQUIRE(cond, ...)                                         \
+    do {                                                                \
+        if (!(cond)) return ::amav::fail(AMAV_ERR_INVALID_ARG, __VA_ARGS__); \
+    } while (0)
+
+// Check the launch that was just enqueued (no device sync: only launch-time errors).
+inline int check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(AMAV_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return AMAV_OK;
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Bump allocator over the caller's workspace; with base == nullptr it only measures.
+struct Carver {
+    char *base;
+    size_t off = 0;
+    explicit Carver(void *b) : base(static_cast<char *>(b)) {}
+    template <typename T>
+    T *take(size_t count) {
+        off = align_up(off, 256);
+        T *p = base ? reinterpret_cast<T *>(base + off) : nullptr;
+        off += count * sizeof(T);
+        return p;
+    }
+    size_t total() const { return align_up(off, 256); }
+};
+
+}  // namespace amav

@@ -1,0 +1,72 @@
+// Library-level entry points of libamav_hip.so (version, errors, device probe) and the camera kernel.
+#include "amav_common.h"
+
+namespace amav {
+
+char *error_buffer() {
+    static thread_local char buf[512] = {0};
+    return buf;
+}
+
+// One thread per frame.  Replaces src/models/renderer.py:486-510 + src/utils/graphic_utils.py:67-78,103-145.
+// The reference inverts [R^T|t] twice (a numerical identity); here the view matrix is E.
+__global__ void camera_kernel(int F, const float *K, const float *E, float h, float w, float znear, float zfar,
+                              float *view, float *proj, float *tanfov, float *campos) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    const float *k = K + f * 9;
+    const float *e = E + f * 16;
+    const float fx = k[0], fy = k[4], px = k[2], py = k[5];
+    const float n[4][4] = {{2.f * fx / w, 0.f, (2.f * px - w) / w, 0.f},
+                           {0.f, 2.f * fy / h, (2.f * py - h) / h, 0.f},
+                           {0.f, 0.f, zfar / (zfar - znear), -zfar * znear / (zfar - znear)},
+                           {0.f, 0.f, 1.f, 0.f}};
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) {
+            view[f * 16 + c * 4 + r] = e[r * 4 + c];
+            float acc = 0.f;
+            for (int m = 0; m < 4; ++m) acc += n[r][m] * e[m * 4 + c];
+            proj[f * 16 + c * 4 + r] = acc;
+        }
+    tanfov[2 * f] = w / (2.f * fx);
+    tanfov[2 * f + 1] = h / (2.f * fy);
+    if (campos) {
+        // camera centre = -A^-1 t for E = [A | t]
+        const float a = e[0], b = e[1], c = e[2], d = e[4], g = e[5], hh = e[6], i = e[8], j = e[9], l = e[10];
+        const float c00 = g * l - hh * j, c01 = hh * i - d * l, c02 = d * j - g * i;
+        const float det = a * c00 + b * c01 + c * c02;
+        const float inv = 1.f / det;
+        const float t0 = e[3], t1 = e[7], t2 = e[11];
+        const float i00 = c00 * inv, i01 = (c * j - b * l) * inv, i02 = (b * hh - c * g) * inv;
+        const float i10 = c01 * inv, i11 = (a * l - c * i) * inv, i12 = (c * d - a * hh) * inv;
+        const float i20 = c02 * inv, i21 = (b * i - a * j) * inv, i22 = (a * g - b * d) * inv;
+        campos[3 * f] = -(i00 * t0 + i01 * t1 + i02 * t2);
+        campos[3 * f + 1] = -(i10 * t0 + i11 * t1 + i12 * t2);
+        campos[3 * f + 2] = -(i20 * t0 + i21 * t1 + i22 * t2);
+    }
+}
+
+}  // namespace amav
+
+using namespace amav;
+
+extern "C" const char *amav_version(void) { return "amav-hip 0.1.0 (gfx950)"; }
+
+extern "C" const char *amav_last_error(void) { return error_buffer(); }
+
+extern "C" int amav_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail(AMAV_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    return n;
+}
+
+extern "C" int amav_camera_from_intrinsics(int F, const float *K, const float *E, int height, int width, float znear,
+                                           float zfar, float *view, float *proj, float *tanfov, float *campos,
+                                           void *stream) {
+    AMAV_REQUIRE(F > 0 && height > 0 && width > 0, "amav_camera_from_intrinsics: bad sizes");
+    AMAV_REQUIRE(K && E && view && proj && tanfov, "amav_camera_from_intrinsics: NULL pointer");
+    camera_kernel<<<(F + 63) / 64, 64, 0, static_cast<hipStream_t>(stream)>>>(F, K, E, (float)height, (float)width,
+                                                                             znear, zfar, view, proj, tanfov, campos);
+    return check_launch("amav_camera_from_intrinsics");
+}

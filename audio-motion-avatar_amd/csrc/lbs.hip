@@ -1,0 +1,294 @@
+// SMPL-X forward + linear blend skinning for gfx950, F frames per launch.
+//
+// Replaces smplx.SMPLX.forward -> smplx.lbs.lbs as the reference reaches it (src/models/renderer.py:261-274) and
+// the posed-mesh subdivision + subset that follows (renderer.py:276-288).  SURVEY.md Appendix A.2 is the spec.
+//
+//   joint_chain_kernel  one 64-lane block per frame, one lane per joint: Rodrigues (angle = ||r + 1e-8||), joint
+//                       locations from the pre-regressed tables, the kinematic chain level by level in LDS, the
+//                       rest-pose-removed 3x4 transforms A_j, and the frame's blend feature column
+//                       [betas; expression; (R_1..R_54 - I)] written TRANSPOSED ([k][frame]) so the skin kernel can
+//                       fetch 16 frames of one feature with a single scalar load.
+//   skin_kernel         one thread per vertex and FT frames: the [F, 506] x [506, 3V] blend product is done as
+//                       register-tiled FMAs whose frame operand is wave-uniform (SGPR), so the 63.6 MB blend table
+//                       is streamed once per FT frames, coalesced (12 B per lane); then T_v = sum_j w_vj A_j from
+//                       LDS and the 3x4 transform.  Nothing but the vertices is written.
+//   gather_kernel       baked subdivision table -> the N sampled points.
+#include "amav_common.h"
+
+namespace amav {
+namespace lbs {
+
+constexpr int kMaxJoints = 64;
+
+struct Tables {
+    int V, J, NC, KW, KB;  // KB = NC + (J-1)*9 blend rows
+    const float *v_template, *blend, *j_template, *j_dirs;
+    const int *parents, *skin_idx;
+    const float *skin_w;
+};
+
+__global__ __launch_bounds__(64) void joint_chain_kernel(Tables t, int F, int Fpad, const float *__restrict__ full_pose,
+                                                        const float *__restrict__ coeffs, float *__restrict__ featT,
+                                                        float *__restrict__ A_out) {
+    __shared__ float G[kMaxJoints][12];
+    __shared__ float coef[64];
+    __shared__ int depth_s[kMaxJoints];
+    const int f = blockIdx.x, j = threadIdx.x;
+    if (j < t.NC) {
+        const float c = coeffs[(size_t)f * t.NC + j];
+        coef[j] = c;
+        featT[(size_t)j * Fpad + f] = c;
+    }
+    __syncthreads();
+    float R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    float Jp[3] = {0, 0, 0}, rel[3] = {0, 0, 0};
+    int parent = -1, depth = 0;
+    if (j < t.J) {
+        // Rodrigues, smplx.lbs.batch_rodrigues: eps is added to every component before the norm
+        const float rx = full_pose[(size_t)f * t.J * 3 + j * 3], ry = full_pose[(size_t)f * t.J * 3 + j * 3 + 1],
+                    rz = full_pose[(size_t)f * t.J * 3 + j * 3 + 2];
+        const float ex = rx + 1e-8f, ey = ry + 1e-8f, ez = rz + 1e-8f;
+        const float angle = sqrtf(ex * ex + ey * ey + ez * ez);
+        const float kx = rx / angle, ky = ry / angle, kz = rz / angle;
+        const float s = sinf(angle), c1 = 1.0f - cosf(angle);
+        // K = [[0,-kz,ky],[kz,0,-kx],[-ky,kx,0]];  R = I + s K + (1-c) K K
+        R[0] = 1.0f + c1 * (-kz * kz - ky * ky);
+        R[1] = -s * kz + c1 * (kx * ky);
+        R[2] = s * ky + c1 * (kx * kz);
+        R[3] = s * kz + c1 * (kx * ky);
+        R[4] = 1.0f + c1 * (-kz * kz - kx * kx);
+        R[5] = -s * kx + c1 * (ky * kz);
+        R[6] = -s * ky + c1 * (kx * kz);
+        R[7] = s * kx + c1 * (ky * kz);
+        R[8] = 1.0f + c1 * (-ky * ky - kx * kx);
+        if (j >= 1) {
+            float *dst = featT + (size_t)(t.NC + (j - 1) * 9) * Fpad + f;
+#pragma unroll
+            for (int e = 0; e < 9; ++e) dst[(size_t)e * Fpad] = R[e] - ((e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f);
+        }
+        // joint location: J = J_regressor (v_template + dirs c) = j_template + j_dirs c
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            float acc = t.j_template[j * 3 + d];
+            const float *row = t.j_dirs + (size_t)(j * 3 + d) * t.NC;
+            for (int l = 0; l < t.NC; ++l) acc += row[l] * coef[l];
+            Jp[d] = acc;
+        }
+        parent = t.parents[j];
+        for (int a = parent; a >= 0; a = t.parents[a]) ++depth;
+        depth_s[j] = depth;
+        G[j][0] = Jp[0], G[j][1] = Jp[1], G[j][2] = Jp[2];  // park J_j for the children
+    }
+    __syncthreads();
+    int max_depth = 0;
+    for (int k = 0; k < t.J; ++k) max_depth = max(max_depth, depth_s[k]);
+    if (j < t.J && parent >= 0) {
+        rel[0] = Jp[0] - G[parent][0], rel[1] = Jp[1] - G[parent][1], rel[2] = Jp[2] - G[parent][2];
+    } else {
+        rel[0] = Jp[0], rel[1] = Jp[1], rel[2] = Jp[2];
+    }
+    __syncthreads();
+    // chain: G_j = G_parent [R_j | rel_j], level by level
+    float Gj[12];
+    if (j < t.J && depth == 0) {
+        Gj[0] = R[0], Gj[1] = R[1], Gj[2] = R[2], Gj[3] = rel[0];
+        Gj[4] = R[3], Gj[5] = R[4], Gj[6] = R[5], Gj[7] = rel[1];
+        Gj[8] = R[6], Gj[9] = R[7], Gj[10] = R[8], Gj[11] = rel[2];
+#pragma unroll
+        for (int e = 0; e < 12; ++e) G[j][e] = Gj[e];
+    }
+    __syncthreads();
+    for (int d = 1; d <= max_depth; ++d) {
+        if (j < t.J && depth == d) {
+            const float *P = G[parent];  // depth d-1: final since the previous barrier
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const float p0 = P[r * 4], p1 = P[r * 4 + 1], p2 = P[r * 4 + 2], p3 = P[r * 4 + 3];
+                Gj[r * 4 + 0] = p0 * R[0] + p1 * R[3] + p2 * R[6];
+                Gj[r * 4 + 1] = p0 * R[1] + p1 * R[4] + p2 * R[7];
+                Gj[r * 4 + 2] = p0 * R[2] + p1 * R[5] + p2 * R[8];
+                Gj[r * 4 + 3] = p0 * rel[0] + p1 * rel[1] + p2 * rel[2] + p3;
+            }
+#pragma unroll
+            for (int e = 0; e < 12; ++e) G[j][e] = Gj[e];
+        }
+        __syncthreads();
+    }
+    if (j < t.J) {
+        // remove the rest pose: translation -= G[:3,:3] J_j
+        float *dst = A_out + ((size_t)f * t.J + j) * 12;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            dst[r * 4 + 0] = Gj[r * 4 + 0];
+            dst[r * 4 + 1] = Gj[r * 4 + 1];
+            dst[r * 4 + 2] = Gj[r * 4 + 2];
+            dst[r * 4 + 3] = Gj[r * 4 + 3] - (Gj[r * 4] * Jp[0] + Gj[r * 4 + 1] * Jp[1] + Gj[r * 4 + 2] * Jp[2]);
+        }
+    }
+}
+
+// grid: (ceil(V/256), Fpad/FT).  featT rows are [k][Fpad]; A is [F][J][12].
+template <int FT>
+__global__ __launch_bounds__(256) void skin_kernel(Tables t, int F, int Fpad, const float *__restrict__ featT,
+                                                   const float *__restrict__ A, float *__restrict__ out) {
+    extern __shared__ __align__(16) float A_lds[];  // [FT][J][12]
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    const int f0 = blockIdx.y * FT;
+    const int nA = FT * t.J * 12;
+    for (int k = threadIdx.x; k < nA; k += blockDim.x) {
+        const int ff = f0 + k / (t.J * 12);
+        A_lds[k] = ff < F ? A[(size_t)f0 * t.J * 12 + k] : 0.0f;
+    }
+    __syncthreads();
+    if (v >= t.V) return;
+
+    float acc[FT][3];
+    {
+        const float x = t.v_template[v * 3], y = t.v_template[v * 3 + 1], z = t.v_template[v * 3 + 2];
+#pragma unroll
+        for (int m = 0; m < FT; ++m) acc[m][0] = x, acc[m][1] = y, acc[m][2] = z;
+    }
+    const float *bl = t.blend + (size_t)v * 3;
+    const size_t row = (size_t)t.V * 3;
+#pragma unroll 2
+    for (int k = 0; k < t.KB; ++k) {
+        const float b0 = bl[k * row], b1 = bl[k * row + 1], b2 = bl[k * row + 2];
+        const float *fk = featT + (size_t)k * Fpad + f0;  // wave-uniform address -> scalar loads
+#pragma unroll
+        for (int m = 0; m < FT; ++m) {
+            const float s = fk[m];
+            acc[m][0] += s * b0;
+            acc[m][1] += s * b1;
+            acc[m][2] += s * b2;
+        }
+    }
+
+    // the vertex's non-zero skinning weights (ascending joint order); 8 live in registers, any more are re-read
+    int jidx[8];
+    float jw[8];
+    const int kw = t.KW;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        jidx[k] = k < kw ? t.skin_idx[(size_t)v * kw + k] : 0;
+        jw[k] = k < kw ? t.skin_w[(size_t)v * kw + k] : 0.0f;
+    }
+#pragma unroll
+    for (int m = 0; m < FT; ++m) {
+        if (f0 + m >= F) break;
+        float Tm[12];
+#pragma unroll
+        for (int e = 0; e < 12; ++e) Tm[e] = 0.0f;
+        const float *Af = A_lds + m * t.J * 12;
+        auto add = [&](int ji, float w) {
+            const float4 *a4 = reinterpret_cast<const float4 *>(Af + ji * 12);
+            const float4 r0 = a4[0], r1 = a4[1], r2 = a4[2];
+            Tm[0] += w * r0.x, Tm[1] += w * r0.y, Tm[2] += w * r0.z, Tm[3] += w * r0.w;
+            Tm[4] += w * r1.x, Tm[5] += w * r1.y, Tm[6] += w * r1.z, Tm[7] += w * r1.w;
+            Tm[8] += w * r2.x, Tm[9] += w * r2.y, Tm[10] += w * r2.z, Tm[11] += w * r2.w;
+        };
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (k < kw) add(jidx[k], jw[k]);
+        for (int k = 8; k < kw; ++k) add(t.skin_idx[(size_t)v * kw + k], t.skin_w[(size_t)v * kw + k]);
+        const float x = acc[m][0], y = acc[m][1], z = acc[m][2];
+        float *o = out + ((size_t)(f0 + m) * t.V + v) * 3;
+        o[0] = Tm[0] * x + Tm[1] * y + Tm[2] * z + Tm[3];
+        o[1] = Tm[4] * x + Tm[5] * y + Tm[6] * z + Tm[7];
+        o[2] = Tm[8] * x + Tm[9] * y + Tm[10] * z + Tm[11];
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_kernel(int V, int N, const float *__restrict__ verts,
+                                                     const int4 *__restrict__ idx, float *__restrict__ out) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = blockIdx.y;
+    if (n >= N) return;
+    const int4 id = idx[n];
+    const float *vf = verts + (size_t)f * V * 3;
+    float *o = out + ((size_t)f * N + n) * 3;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float p0 = (vf[id.x * 3 + d] + vf[id.y * 3 + d]) * 0.5f;
+        const float p1 = (vf[id.z * 3 + d] + vf[id.w * 3 + d]) * 0.5f;
+        o[d] = (p0 + p1) * 0.5f;
+    }
+}
+
+static int frame_tile(int F) { return F <= 8 ? 4 : 16; }
+
+}  // namespace lbs
+}  // namespace amav
+
+using namespace amav;
+using namespace amav::lbs;
+
+static int validate_tables(const amav_body_tables *t, const char *who) {
+    AMAV_REQUIRE(t != nullptr, "%s: tables is NULL", who);
+    AMAV_REQUIRE(t->num_verts > 0 && t->num_joints > 0 && t->num_joints <= kMaxJoints, "%s: bad V=%d J=%d", who,
+                 t->num_verts, t->num_joints);
+    AMAV_REQUIRE(t->num_coeffs > 0 && t->num_coeffs <= 64, "%s: num_coeffs %d not in 1..64", who, t->num_coeffs);
+    AMAV_REQUIRE(t->skin_k > 0 && t->skin_k <= t->num_joints, "%s: bad skin_k %d", who, t->skin_k);
+    AMAV_REQUIRE(t->v_template && t->blend && t->j_template && t->j_dirs && t->parents && t->skin_idx && t->skin_w,
+                 "%s: NULL table", who);
+    return AMAV_OK;
+}
+
+static size_t lbs_ws(int F, const amav_body_tables *t, float **featT, float **A, void *ws) {
+    const int FT = frame_tile(F);
+    const int Fpad = (F + FT - 1) / FT * FT;
+    const int KB = t->num_coeffs + (t->num_joints - 1) * 9;
+    Carver c(ws);
+    float *ft = c.take<float>((size_t)KB * Fpad);
+    float *a = c.take<float>((size_t)Fpad * t->num_joints * 12);
+    if (featT) *featT = ft;
+    if (A) *A = a;
+    return c.total();
+}
+
+extern "C" size_t amav_lbs_workspace_bytes(int F, const amav_body_tables *t) {
+    if (F <= 0 || validate_tables(t, "amav_lbs_workspace_bytes") != AMAV_OK) return 0;
+    return lbs_ws(F, t, nullptr, nullptr, nullptr);
+}
+
+extern "C" int amav_lbs_forward(int F, const amav_body_tables *tb, const float *full_pose, const float *coeffs,
+                                float *out_vertices, float *out_A, void *workspace, size_t workspace_bytes,
+                                void *stream_) {
+    AMAV_REQUIRE(F > 0, "amav_lbs_forward: F=%d", F);
+    if (int rc = validate_tables(tb, "amav_lbs_forward")) return rc;
+    AMAV_REQUIRE(full_pose && coeffs && out_vertices && workspace, "amav_lbs_forward: NULL pointer");
+    float *featT = nullptr, *A = nullptr;
+    const size_t need = lbs_ws(F, tb, &featT, &A, workspace);
+    if (workspace_bytes < need)
+        return fail(AMAV_ERR_WORKSPACE, "amav_lbs_forward: workspace %zu < required %zu", workspace_bytes, need);
+    Tables t;
+    t.V = tb->num_verts, t.J = tb->num_joints, t.NC = tb->num_coeffs, t.KW = tb->skin_k;
+    t.KB = t.NC + (t.J - 1) * 9;
+    t.v_template = tb->v_template, t.blend = tb->blend, t.j_template = tb->j_template, t.j_dirs = tb->j_dirs;
+    t.parents = tb->parents, t.skin_idx = tb->skin_idx, t.skin_w = tb->skin_w;
+    const int FT = frame_tile(F);
+    const int Fpad = (F + FT - 1) / FT * FT;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    // padded frame columns of featT must be finite (they feed FMAs whose results are discarded)
+    if (Fpad != F && hipMemsetAsync(featT, 0, (size_t)t.KB * Fpad * sizeof(float), stream) != hipSuccess)
+        return fail(AMAV_ERR_LAUNCH, "amav_lbs_forward: hipMemsetAsync failed");
+    float *A_dst = out_A ? out_A : A;
+    joint_chain_kernel<<<F, 64, 0, stream>>>(t, F, Fpad, full_pose, coeffs, featT, A_dst);
+    const dim3 grid((t.V + 255) / 256, Fpad / FT);
+    const size_t lds = (size_t)FT * t.J * 12 * sizeof(float);
+    if (FT == 4)
+        skin_kernel<4><<<grid, 256, lds, stream>>>(t, F, Fpad, featT, A_dst, out_vertices);
+    else
+        skin_kernel<16><<<grid, 256, lds, stream>>>(t, F, Fpad, featT, A_dst, out_vertices);
+    return check_launch("amav_lbs_forward");
+}
+
+extern "C" int amav_points_gather(int F, int V, int N, const float *vertices, const int32_t *idx, float *out,
+                                  void *stream) {
+    AMAV_REQUIRE(F > 0 && V > 0 && N > 0, "amav_points_gather: bad sizes");
+    AMAV_REQUIRE(vertices && idx && out, "amav_points_gather: NULL pointer");
+    AMAV_REQUIRE((reinterpret_cast<uintptr_t>(idx) & 15) == 0, "amav_points_gather: idx not 16-B aligned");
+    const dim3 grid((N + 255) / 256, F);
+    gather_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(V, N, vertices, reinterpret_cast<const int4 *>(idx),
+                                                                    out);
+    return check_launch("amav_points_gather");
+}

@@ -1,0 +1,243 @@
+// Triplane decode for gfx950: grid_sample x 3 planes + five linear Gaussian heads + construct_gaussians.
+//
+// Replaces src/models/renderer.py:136,158 (F.grid_sample, bilinear, align_corners=False, zero padding, via
+// sample_from_triplane :292-317), :165-171 (xyz/rotation/scaling/opacity/shs heads on [p; features]) and :319-346
+// (construct_gaussians).  The reference materialises [N, 3C] features (30.7 MB per frame at C=256, N=10k) from an
+// NCHW gather that touches C strided addresses per tap.  Here the two linear maps are swapped:
+//
+//   project_kernel        G[plane][texel][16] = W_plane[16 x C] . slab[:, texel]   -- streams the frame's token slab
+//                         [C][3 R^2] exactly once, fully coalesced (16 B per lane along the texel axis), with the
+//                         weights as wave-uniform (scalar) operands.  This is the HBM-bound kernel of the stage.
+//   sample_decode_kernel  4 lanes per point, each lane owns 4 of the 16 projected channels: 12 taps x 16 B loads
+//                         from the L2-resident projected planes, + W_xyz p + bias, then the per-head epilogue
+//                         (normalise rot, sigmoid colour, xyz + offset + transl) and one packed 64-byte record.
+//
+// Same real-number function as the reference; rounding differs only by summation order.
+#include "amav_common.h"
+
+namespace amav {
+namespace triplane {
+
+// grid: (ceil(R*R/4 / 256), 3, F); each thread projects 4 consecutive texels of one plane.
+__global__ __launch_bounds__(256) void project_kernel(int C, int RR, const float *__restrict__ tokens,
+                                                      long long frame_stride, const float *__restrict__ wplane,
+                                                      float *__restrict__ out) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;  // texel quad within the plane
+    const int plane = blockIdx.y, f = blockIdx.z;
+    if (q * 4 >= RR) return;
+    const int S = 3 * RR;
+    const float *src = tokens + (size_t)f * frame_stride + (size_t)plane * RR + (size_t)q * 4;
+    const float *w = wplane + (size_t)plane * C * 16;  // [C][16], wave-uniform
+    float acc[4][16];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int o = 0; o < 16; ++o) acc[t][o] = 0.0f;
+#pragma unroll 4
+    for (int c = 0; c < C; ++c) {
+        const float4 x = *reinterpret_cast<const float4 *>(src + (size_t)c * S);
+        const float *wc = w + c * 16;
+#pragma unroll
+        for (int o = 0; o < 16; ++o) {
+            const float ww = wc[o];
+            acc[0][o] += ww * x.x;
+            acc[1][o] += ww * x.y;
+            acc[2][o] += ww * x.z;
+            acc[3][o] += ww * x.w;
+        }
+    }
+    float4 *dst = reinterpret_cast<float4 *>(out + (((size_t)f * 3 + plane) * RR + (size_t)q * 4) * 16);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            dst[t * 4 + g] = make_float4(acc[t][g * 4], acc[t][g * 4 + 1], acc[t][g * 4 + 2], acc[t][g * 4 + 3]);
+}
+
+// scalar fallback for R*R not a multiple of 4 or unaligned slabs: one texel per thread
+__global__ __launch_bounds__(256) void project_kernel_scalar(int C, int RR, const float *__restrict__ tokens,
+                                                             long long frame_stride,
+                                                             const float *__restrict__ wplane,
+                                                             float *__restrict__ out) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    const int plane = blockIdx.y, f = blockIdx.z;
+    if (s >= RR) return;
+    const int S = 3 * RR;
+    const float *src = tokens + (size_t)f * frame_stride + (size_t)plane * RR + s;
+    const float *w = wplane + (size_t)plane * C * 16;
+    float acc[16];
+#pragma unroll
+    for (int o = 0; o < 16; ++o) acc[o] = 0.0f;
+    for (int c = 0; c < C; ++c) {
+        const float x = src[(size_t)c * S];
+#pragma unroll
+        for (int o = 0; o < 16; ++o) acc[o] += w[c * 16 + o] * x;
+    }
+    float *dst = out + (((size_t)f * 3 + plane) * RR + s) * 16;
+#pragma unroll
+    for (int o = 0; o < 16; ++o) dst[o] = acc[o];
+}
+
+// torch grid_sampler, bilinear, align_corners=False, padding zeros: pixel = ((g + 1) * size - 1) / 2
+struct Taps {
+    int ix0, iy0;
+    float wx0, wx1, wy0, wy1;
+};
+
+__device__ __forceinline__ Taps make_taps(float gx, float gy, int R) {
+    const float ix = ((gx + 1.0f) * (float)R - 1.0f) * 0.5f;
+    const float iy = ((gy + 1.0f) * (float)R - 1.0f) * 0.5f;
+    const float fx = floorf(ix), fy = floorf(iy);
+    Taps t;
+    t.ix0 = (int)fx, t.iy0 = (int)fy;
+    t.wx1 = ix - fx, t.wx0 = (fx + 1.0f) - ix;
+    t.wy1 = iy - fy, t.wy0 = (fy + 1.0f) - iy;
+    return t;
+}
+
+// grid: (ceil(4N/256), F).  Lane group of 4 per point; lane q owns projected channels 4q..4q+3:
+//   q0 = (xyz_offset, opacity), q1 = rotation, q2 = (scaling, pad), q3 = (shs, pad)
+__global__ __launch_bounds__(256) void sample_decode_kernel(int N, int R, const float *__restrict__ proj,
+                                                            const float *__restrict__ points,
+                                                            const float *__restrict__ transl, float radius, const float *__restrict__ wpoint,
+                                                            float *__restrict__ out) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = gid >> 2, q = gid & 3;
+    const int f = blockIdx.y;
+    if (n >= N) return;
+    const float *pp = points + ((size_t)f * N + n) * 3;
+    const float p0 = pp[0], p1 = pp[1], p2 = pp[2];
+    const float u0 = fminf(fmaxf(p0 / radius, -1.0f), 1.0f);
+    const float u1 = fminf(fmaxf(p1 / radius, -1.0f), 1.0f);
+    const float u2 = fminf(fmaxf(p2 / radius, -1.0f), 1.0f);
+    const int RR = R * R;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int plane = 0; plane < 3; ++plane) {
+        // plane 0 <- (x, y), plane 1 <- (x, z), plane 2 <- (y, z); grid x indexes W, grid y indexes H
+        const float gx = plane == 2 ? u1 : u0;
+        const float gy = plane == 0 ? u1 : u2;
+        const Taps t = make_taps(gx, gy, R);
+        const float4 *pl = reinterpret_cast<const float4 *>(proj + (((size_t)f * 3 + plane) * RR) * 16) + q;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int ix = t.ix0 + dx, iy = t.iy0 + dy;
+                if (ix >= 0 && ix < R && iy >= 0 && iy < R) {
+                    const float w = (dx ? t.wx1 : t.wx0) * (dy ? t.wy1 : t.wy0);
+                    const float4 v = pl[(size_t)(iy * R + ix) * 4];
+                    acc.x += w * v.x, acc.y += w * v.y, acc.z += w * v.z, acc.w += w * v.w;
+                }
+            }
+    }
+    // + W_xyz p + bias  (wpoint [16][4]: 3 xyz weights, bias)
+    const float4 *wp = reinterpret_cast<const float4 *>(wpoint) + q * 4;
+    const float4 w0 = wp[0], w1 = wp[1], w2 = wp[2], w3 = wp[3];
+    acc.x += w0.x * p0 + w0.y * p1 + w0.z * p2 + w0.w;
+    acc.y += w1.x * p0 + w1.y * p1 + w1.z * p2 + w1.w;
+    acc.z += w2.x * p0 + w2.y * p1 + w2.z * p2 + w2.w;
+    acc.w += w3.x * p0 + w3.y * p1 + w3.z * p2 + w3.w;
+
+    float4 rec;
+    if (q == 0) {
+        float tx = 0.f, ty = 0.f, tz = 0.f;
+        if (transl) tx = transl[f * 3], ty = transl[f * 3 + 1], tz = transl[f * 3 + 2];
+        rec = make_float4(p0 + acc.x + tx, p1 + acc.y + ty, p2 + acc.z + tz, acc.w);
+    } else if (q == 1) {
+        // F.normalize(dim=-1): v / max(||v||, 1e-12)
+        const float nrm = fmaxf(sqrtf(acc.x * acc.x + acc.y * acc.y + acc.z * acc.z + acc.w * acc.w), 1e-12f);
+        rec = make_float4(acc.x / nrm, acc.y / nrm, acc.z / nrm, acc.w / nrm);
+    } else if (q == 2) {
+        rec = make_float4(acc.x, acc.y, acc.z, 0.0f);
+    } else {
+        rec = make_float4(1.0f / (1.0f + expf(-acc.x)), 1.0f / (1.0f + expf(-acc.y)), 1.0f / (1.0f + expf(-acc.z)),
+                          0.0f);
+    }
+    reinterpret_cast<float4 *>(out)[((size_t)f * N + n) * 4 + q] = rec;
+}
+
+// Plain sample_from_triplane: grid (N, F), lanes along the 3C output channels (coalesced writes).
+__global__ __launch_bounds__(256) void sample_features_kernel(int N, int C, int R, const float *__restrict__ planes,
+                                                              long long frame_stride, long long plane_stride,
+                                                              long long chan_stride, const float *__restrict__ points,
+                                                              float radius,
+                                                              float *__restrict__ out) {
+    const int n = blockIdx.x, f = blockIdx.y;
+    const float *pp = points + ((size_t)f * N + n) * 3;
+    const float u0 = fminf(fmaxf(pp[0] / radius, -1.0f), 1.0f);
+    const float u1 = fminf(fmaxf(pp[1] / radius, -1.0f), 1.0f);
+    const float u2 = fminf(fmaxf(pp[2] / radius, -1.0f), 1.0f);
+    for (int oc = threadIdx.x; oc < 3 * C; oc += blockDim.x) {
+        const int plane = oc / C, c = oc - plane * C;
+        const float gx = plane == 2 ? u1 : u0;
+        const float gy = plane == 0 ? u1 : u2;
+        const Taps t = make_taps(gx, gy, R);
+        const float *pl = planes + (size_t)f * frame_stride + (size_t)c * chan_stride + (size_t)plane * plane_stride;
+        float acc = 0.0f;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int ix = t.ix0 + dx, iy = t.iy0 + dy;
+                if (ix >= 0 && ix < R && iy >= 0 && iy < R)
+                    acc += pl[iy * R + ix] * ((dx ? t.wx1 : t.wx0) * (dy ? t.wy1 : t.wy0));
+            }
+        out[((size_t)f * N + n) * 3 * C + oc] = acc;
+    }
+}
+
+}  // namespace triplane
+}  // namespace amav
+
+using namespace amav;
+using namespace amav::triplane;
+
+extern "C" int amav_triplane_project(int F, int C, int R, const float *tokens, int64_t frame_stride,
+                                     const float *wplane, float *out, void *stream_) {
+    AMAV_REQUIRE(F > 0 && C > 0 && R > 0, "amav_triplane_project: bad sizes F=%d C=%d R=%d", F, C, R);
+    AMAV_REQUIRE(tokens && wplane && out, "amav_triplane_project: NULL pointer");
+    AMAV_REQUIRE(F <= 65535, "amav_triplane_project: F=%d exceeds grid.z", F);
+    AMAV_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0, "amav_triplane_project: out not 16-B aligned");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int RR = R * R;
+    const bool vec = (RR % 4 == 0) && (frame_stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(tokens) & 15) == 0);
+    if (vec) {
+        const dim3 grid((RR / 4 + 255) / 256, 3, F);
+        project_kernel<<<grid, 256, 0, stream>>>(C, RR, tokens, frame_stride, wplane, out);
+    } else {
+        const dim3 grid((RR + 255) / 256, 3, F);
+        project_kernel_scalar<<<grid, 256, 0, stream>>>(C, RR, tokens, frame_stride, wplane, out);
+    }
+    return check_launch("amav_triplane_project");
+}
+
+extern "C" int amav_triplane_sample_decode(int F, int N, int R, const float *proj, const float *points,
+                                           const float *transl, float radius, const float *wpoint, float *out,
+                                           void *stream_) {
+    AMAV_REQUIRE(F > 0 && N > 0 && R > 0, "amav_triplane_sample_decode: bad sizes");
+    AMAV_REQUIRE(F <= 65535, "amav_triplane_sample_decode: F=%d exceeds grid.y", F);
+    AMAV_REQUIRE(proj && points && wpoint && out, "amav_triplane_sample_decode: NULL pointer");
+    AMAV_REQUIRE(radius > 0.0f, "amav_triplane_sample_decode: radius must be positive");
+    AMAV_REQUIRE(((reinterpret_cast<uintptr_t>(proj) | reinterpret_cast<uintptr_t>(out) |
+                   reinterpret_cast<uintptr_t>(wpoint)) & 15) == 0,
+                 "amav_triplane_sample_decode: proj/out/head_w_point not 16-B aligned");
+    const dim3 grid((unsigned)(((size_t)N * 4 + 255) / 256), F);
+    sample_decode_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream_)>>>(N, R, proj, points, transl, radius,
+                                                                             wpoint, out);
+    return check_launch("amav_triplane_sample_decode");
+}
+
+extern "C" int amav_triplane_sample_features(int F, int N, int C, int R, const float *planes, int64_t frame_stride,
+                                             int64_t plane_stride, int64_t chan_stride, const float *points, float radius, float *out,
+                                             void *stream_) {
+    AMAV_REQUIRE(F > 0 && N > 0 && C > 0 && R > 0, "amav_triplane_sample_features: bad sizes");
+    AMAV_REQUIRE(F <= 65535, "amav_triplane_sample_features: F=%d exceeds grid.y", F);
+    AMAV_REQUIRE(planes && points && out, "amav_triplane_sample_features: NULL pointer");
+    AMAV_REQUIRE(radius > 0.0f, "amav_triplane_sample_features: radius must be positive");
+    const dim3 grid(N, F);
+    sample_features_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream_)>>>(N, C, R, planes, frame_stride,
+                                                                               plane_stride, chan_stride, points,
+                                                                               radius, out);
+    return check_launch("amav_triplane_sample_features");
+}

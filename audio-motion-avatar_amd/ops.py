@@ -1,0 +1,300 @@
+"""Tensor-level wrappers over the C ABI (include/amav.h).  torch is used for device memory and streams only.
+
+Every function requires CUDA(HIP) float32 tensors and raises on anything else: there is no CPU path.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import AmavError, Attr, BodyTables, RasterArgs, check
+
+SCALE_BIAS = 3.9    # src/models/renderer.py:428
+OPACITY_BIAS = 0.0  # src/models/renderer.py:429
+SCALE_MAX = 0.1     # src/models/renderer.py:532
+GAUSS_STRIDE = 16   # floats per packed Gaussian record (AMAV_GAUSS_STRIDE)
+# channel offsets inside a packed record
+REC_XYZ, REC_OPACITY, REC_ROT, REC_SCALE, REC_COLOR = 0, 3, 4, 8, 12
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need(t: torch.Tensor, name: str, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor):
+        raise AmavError(f"{name}: expected a torch.Tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise AmavError(f"{name}: tensor is on {t.device}; this package only runs on an MI355X (HIP) device")
+    if t.dtype != dtype:
+        raise AmavError(f"{name}: dtype {t.dtype}, expected {dtype}")
+    return t
+
+
+def _contig(t, name, dtype=torch.float32):
+    t = _need(t, name, dtype)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _attr(t: torch.Tensor, name: str, width: int) -> Attr:
+    """[F,N,width] tensor (any frame/element strides, unit stride on the last axis) -> amav_attr."""
+    _need(t, name)
+    if t.dim() != 3 or t.shape[2] != width:
+        raise AmavError(f"{name}: expected [F,N,{width}], got {tuple(t.shape)}")
+    if width > 1 and t.stride(2) != 1:
+        t = t.contiguous()
+    return Attr(t.data_ptr(), t.stride(0), t.stride(1), 0), t
+
+
+# --------------------------------------------------------------------------------------------------------- camera
+def camera_from_intrinsics(K, E, height, width, znear=0.01, zfar=100.0):
+    """K [F,3,3], E [F,4,4] -> (viewmatrix [F,16], projmatrix [F,16], tanfov [F,2], campos [F,3]); no host sync.
+
+    Replaces src/models/renderer.py:486-510 (which costs >= 6 host syncs per frame in the reference).
+    """
+    K = _contig(K.reshape(-1, 3, 3), "K")
+    E = _contig(E.reshape(-1, 4, 4), "E")
+    F = K.shape[0]
+    if E.shape[0] != F:
+        raise AmavError(f"camera: {F} intrinsics vs {E.shape[0]} extrinsics")
+    dev = K.device
+    view = torch.empty(F, 16, device=dev)
+    proj = torch.empty(F, 16, device=dev)
+    tanfov = torch.empty(F, 2, device=dev)
+    campos = torch.empty(F, 3, device=dev)
+    check(_lib.lib().amav_camera_from_intrinsics(F, K.data_ptr(), E.data_ptr(), int(height), int(width), znear, zfar,
+                                                 view.data_ptr(), proj.data_ptr(), tanfov.data_ptr(),
+                                                 campos.data_ptr(), _stream()), "amav_camera_from_intrinsics")
+    return view, proj, tanfov, campos
+
+
+# ----------------------------------------------------------------------------------------------------- rasterizer
+class RasterWorkspace:
+    """Caller-owned scratch of the rasterizer for one problem size (reusable across calls and hipGraph-safe)."""
+
+    def __init__(self, num_frames, num_gaussians, height, width, instance_capacity, device):
+        self.key = (num_frames, num_gaussians, height, width)
+        self.capacity = int(instance_capacity)
+        nbytes = _lib.lib().amav_rasterize_workspace_bytes(num_frames, num_gaussians, height, width, self.capacity)
+        if nbytes == 0:
+            raise AmavError(f"amav_rasterize_workspace_bytes rejected {self.key} capacity={self.capacity}")
+        self.buffer = torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+    def status(self):
+        """(total_instances, overflowed) of the last forward.  Synchronises the current stream."""
+        total, over = ctypes.c_int64(0), ctypes.c_int32(0)
+        check(_lib.lib().amav_rasterize_status(self.buffer.data_ptr(), ctypes.byref(total), ctypes.byref(over),
+                                               _stream()), "amav_rasterize_status")
+        return total.value, bool(over.value)
+
+
+def default_instance_capacity(num_frames, num_gaussians, per_gaussian=16):
+    return int(num_frames) * int(num_gaussians) * per_gaussian
+
+
+def rasterize(means3d, rotations, scales, opacities, colors, viewmatrix, projmatrix, tanfov, height, width,
+              bg=(1.0, 1.0, 1.0), apply_activations=False, scale_modifier=1.0, antialiasing=False, clamp_output=False,
+              want_inv_depth=False, want_radii=False, workspace=None, check_overflow=True, out_rgba=None):
+    """Batched tile rasterizer.  Gaussian attributes are [F,N,*] (frame stride 0 = shared across frames).
+
+    Returns dict(rgba [F,H,W,4], inv_depth [F,H,W] | None, radii [F,N] | None, workspace).
+    With check_overflow the call synchronises once to read the instance count and transparently retries with a
+    larger workspace; without it the caller must consult workspace.status() before trusting the output.
+    """
+    a_m, means3d = _attr(means3d, "means3d", 3)
+    a_r, rotations = _attr(rotations, "rotations", 4)
+    a_s, scales = _attr(scales, "scales", 3)
+    a_o, opacities = _attr(opacities, "opacities", 1)
+    a_c, colors = _attr(colors, "colors", 3)
+    F, N = means3d.shape[0], means3d.shape[1]
+    for name, t in (("rotations", rotations), ("scales", scales), ("opacities", opacities), ("colors", colors)):
+        if t.shape[0] != F or t.shape[1] != N:
+            raise AmavError(f"{name}: shape {tuple(t.shape)} does not match means3d [F={F},N={N},3]")
+    viewmatrix = _contig(viewmatrix.reshape(F, 16), "viewmatrix")
+    projmatrix = _contig(projmatrix.reshape(F, 16), "projmatrix")
+    tanfov = _contig(tanfov.reshape(F, 2), "tanfov")
+    dev = means3d.device
+    H, W = int(height), int(width)
+    if out_rgba is None:
+        out_rgba = torch.empty(F, H, W, 4, device=dev)
+    else:
+        _need(out_rgba, "out_rgba")
+        if tuple(out_rgba.shape) != (F, H, W, 4) or not out_rgba.is_contiguous():
+            raise AmavError(f"out_rgba must be contiguous [F,H,W,4] = {(F, H, W, 4)}")
+    inv_depth = torch.empty(F, H, W, device=dev) if want_inv_depth else None
+    radii = torch.empty(F, N, dtype=torch.int32, device=dev) if want_radii else None
+    if workspace is None:
+        workspace = RasterWorkspace(F, N, H, W, default_instance_capacity(F, N), dev)
+    elif workspace.key != (F, N, H, W):
+        raise AmavError(f"workspace was sized for {workspace.key}, call is {(F, N, H, W)}")
+
+    def launch(ws):
+        args = RasterArgs()
+        args.num_frames, args.num_gaussians, args.height, args.width = F, N, H, W
+        args.means3d, args.rotations, args.scales, args.opacities, args.colors = a_m, a_r, a_s, a_o, a_c
+        args.viewmatrix, args.projmatrix, args.tanfov = viewmatrix.data_ptr(), projmatrix.data_ptr(), tanfov.data_ptr()
+        args.bg = (ctypes.c_float * 3)(*[float(b) for b in bg])
+        args.scale_modifier = float(scale_modifier)
+        args.apply_activations = int(bool(apply_activations))
+        args.scale_bias, args.scale_max, args.opacity_bias = SCALE_BIAS, SCALE_MAX, OPACITY_BIAS
+        args.antialiasing = int(bool(antialiasing))
+        args.clamp_output = int(bool(clamp_output))
+        args.out_rgba = out_rgba.data_ptr()
+        args.out_inv_depth = inv_depth.data_ptr() if inv_depth is not None else None
+        args.out_radii = radii.data_ptr() if radii is not None else None
+        args.workspace, args.workspace_bytes = ws.buffer.data_ptr(), ws.buffer.numel()
+        args.instance_capacity = ws.capacity
+        check(_lib.lib().amav_rasterize_forward(ctypes.byref(args), _stream()), "amav_rasterize_forward")
+
+    launch(workspace)
+    if check_overflow:
+        total, over = workspace.status()
+        if over:
+            workspace = RasterWorkspace(F, N, H, W, total, dev)
+            launch(workspace)
+            total, over = workspace.status()
+            if over:
+                raise AmavError(f"rasterizer overflowed twice (instances={total})")
+    return dict(rgba=out_rgba, inv_depth=inv_depth, radii=radii, workspace=workspace)
+
+
+# ------------------------------------------------------------------------------------------------------------ LBS
+def body_tables_struct(tables: dict) -> BodyTables:
+    """dict of device tensors prepared by body_model.BodyModel.device_tables() -> amav_body_tables."""
+    t = BodyTables()
+    t.num_verts, t.num_joints = tables["v_template"].shape[0], tables["parents"].shape[0]
+    t.num_coeffs, t.skin_k = tables["j_dirs"].shape[1], tables["skin_idx"].shape[1]
+    for k in ("v_template", "blend", "j_template", "j_dirs", "skin_w"):
+        setattr(t, k, _contig(tables[k], k).data_ptr())
+    for k in ("parents", "skin_idx"):
+        setattr(t, k, _contig(tables[k], k, torch.int32).data_ptr())
+    return t
+
+
+def lbs_forward(tables: dict, full_pose, coeffs, want_transforms=False):
+    """full_pose [F, J*3], coeffs [F, n_coeff] -> vertices [F,V,3] (and A [F,J,12]).  renderer.py:261-274."""
+    full_pose = _contig(full_pose, "full_pose")
+    coeffs = _contig(coeffs, "coeffs")
+    F = full_pose.shape[0]
+    ts = body_tables_struct(tables)
+    if full_pose.shape != (F, ts.num_joints * 3) or coeffs.shape != (F, ts.num_coeffs):
+        raise AmavError(f"lbs: full_pose {tuple(full_pose.shape)} / coeffs {tuple(coeffs.shape)} do not match "
+                        f"J={ts.num_joints}, n_coeff={ts.num_coeffs}")
+    dev = full_pose.device
+    nbytes = _lib.lib().amav_lbs_workspace_bytes(F, ctypes.byref(ts))
+    if nbytes == 0:
+        raise AmavError("amav_lbs_workspace_bytes rejected the tables: " + _lib.lib().amav_last_error().decode())
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    verts = torch.empty(F, ts.num_verts, 3, device=dev)
+    A = torch.empty(F, ts.num_joints, 12, device=dev) if want_transforms else None
+    check(_lib.lib().amav_lbs_forward(F, ctypes.byref(ts), full_pose.data_ptr(), coeffs.data_ptr(), verts.data_ptr(),
+                                      A.data_ptr() if A is not None else None, ws.data_ptr(), nbytes, _stream()),
+          "amav_lbs_forward")
+    return (verts, A) if want_transforms else verts
+
+
+def points_gather(vertices, idx4):
+    """vertices [F,V,3], idx4 [N,4] int32 -> points [F,N,3] (baked subdivision + subset, renderer.py:276-288)."""
+    vertices = _contig(vertices, "vertices")
+    idx4 = _contig(idx4, "idx4", torch.int32)
+    F, V, _ = vertices.shape
+    N = idx4.shape[0]
+    out = torch.empty(F, N, 3, device=vertices.device)
+    check(_lib.lib().amav_points_gather(F, V, N, vertices.data_ptr(), idx4.data_ptr(), out.data_ptr(), _stream()),
+          "amav_points_gather")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------- triplane
+def pack_head_weights(weights: dict, channels: int, device):
+    """The five head Linear layers (renderer.py:51-55) -> (head_w_plane [3,C,16], head_w_point [16,4]).
+
+    `weights` maps 'xyz_layer' | 'rotation_layer' | 'scaling_layer' | 'opacity_layer' | 'shs_layer' to
+    (weight [out, 3C+3], bias [out]).  Output channel order = packed record layout (include/amav.h).
+    """
+    C = channels
+    rows = {"xyz_layer": (0, 3), "opacity_layer": (3, 1), "rotation_layer": (4, 4), "scaling_layer": (8, 3),
+            "shs_layer": (12, 3)}
+    Wcat = torch.zeros(16, 3 * C + 3, device=device)
+    bias = torch.zeros(16, device=device)
+    for name, (o, n) in rows.items():
+        w, b = weights[name]
+        if tuple(w.shape) != (n, 3 * C + 3):
+            raise AmavError(f"{name}.weight has shape {tuple(w.shape)}, expected {(n, 3 * C + 3)}")
+        Wcat[o:o + n] = w.detach().to(device=device, dtype=torch.float32)
+        bias[o:o + n] = b.detach().to(device=device, dtype=torch.float32)
+    w_plane = Wcat[:, 3:].reshape(16, 3, C).permute(1, 2, 0).contiguous()  # [3, C, 16]
+    w_point = torch.cat([Wcat[:, :3], bias[:, None]], dim=1).contiguous()   # [16, 4]
+    return w_plane, w_point
+
+
+def triplane_project(tokens, head_w_plane, resolution):
+    """tokens [F, C, 3*R*R] (reference token layout, renderer.py:85-91) -> projected planes [F,3,R,R,16]."""
+    _need(tokens, "tokens")
+    if tokens.dim() != 3 or tokens.stride(2) != 1 or tokens.stride(1) != tokens.shape[2]:
+        tokens = tokens.contiguous()
+    F, C, S = tokens.shape
+    R = int(resolution)
+    if S != 3 * R * R:
+        raise AmavError(f"tokens last dim {S} != 3*R*R = {3 * R * R}")
+    head_w_plane = _contig(head_w_plane, "head_w_plane")
+    if tuple(head_w_plane.shape) != (3, C, 16):
+        raise AmavError(f"head_w_plane {tuple(head_w_plane.shape)} != {(3, C, 16)}")
+    out = torch.empty(F, 3, R, R, 16, device=tokens.device)
+    check(_lib.lib().amav_triplane_project(F, C, R, tokens.data_ptr(), tokens.stride(0), head_w_plane.data_ptr(),
+                                           out.data_ptr(), _stream()), "amav_triplane_project")
+    return out
+
+
+def triplane_sample_decode(proj, points, transl, radius, head_w_point):
+    """proj [F,3,R,R,16], points [F,N,3], transl [F,3] | None -> packed Gaussians [F,N,16]."""
+    proj = _contig(proj, "proj")
+    points = _contig(points, "points")
+    head_w_point = _contig(head_w_point, "head_w_point")
+    F, _, R, _, _ = proj.shape
+    N = points.shape[1]
+    if points.shape[0] != F:
+        raise AmavError(f"points has {points.shape[0]} frames, proj has {F}")
+    if transl is not None:
+        transl = _contig(transl.reshape(F, 3), "transl")
+    out = torch.empty(F, N, GAUSS_STRIDE, device=proj.device)
+    check(_lib.lib().amav_triplane_sample_decode(F, N, R, proj.data_ptr(), points.data_ptr(),
+                                                 transl.data_ptr() if transl is not None else None, float(radius),
+                                                 head_w_point.data_ptr(), out.data_ptr(), _stream()),
+          "amav_triplane_sample_decode")
+    return out
+
+
+def triplane_sample_features(planes, points, radius):
+    """planes [F,3,C,R,R] (any strides with unit stride along W and R along H), points [F,N,3] -> [F,N,3C]."""
+    _need(planes, "planes")
+    points = _contig(points, "points")
+    F, P, C, R, R2 = planes.shape
+    if P != 3 or R != R2:
+        raise AmavError(f"planes must be [F,3,C,R,R], got {tuple(planes.shape)}")
+    if planes.stride(4) != 1 or planes.stride(3) != R:
+        planes = planes.contiguous()
+    N = points.shape[1]
+    out = torch.empty(F, N, 3 * C, device=planes.device)
+    check(_lib.lib().amav_triplane_sample_features(F, N, C, R, planes.data_ptr(), planes.stride(0), planes.stride(1),
+                                                   planes.stride(2), points.data_ptr(), float(radius),
+                                                   out.data_ptr(), _stream()), "amav_triplane_sample_features")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------ attention
+def selfattn(q, k, v, heads, scale=None):
+    """softmax(q k^T * scale) v for [B,S,H*D] fp32 tensors (row stride may exceed H*D), D = 64."""
+    for name, t in (("q", q), ("k", k), ("v", v)):
+        _need(t, name)
+        if t.dim() != 3 or t.stride(2) != 1 or t.stride(0) != t.shape[1] * t.stride(1):
+            raise AmavError(f"{name}: need [B,S,H*D] with unit inner stride and dense batch stride")
+    B, S, HD = q.shape
+    D = HD // heads
+    if k.shape != q.shape or v.shape != q.shape or not (q.stride(1) == k.stride(1) == v.stride(1)):
+        raise AmavError("selfattn: q, k, v must share shape and row stride")
+    out = torch.empty(B, S, HD, device=q.device)
+    check(_lib.lib().amav_selfattn_forward(B, S, heads, D, q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(1),
+                                           out.data_ptr(), HD, float(scale if scale is not None else D ** -0.5),
+                                           _stream()), "amav_selfattn_forward")
+    return out

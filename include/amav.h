@@ -1,0 +1,186 @@
+/*
+ * amav.h -- C ABI of libamav_hip.so: the MI355X (gfx950) kernels of the audio-driven avatar rendering hot path.
+ *
+ * The reference (liubingqi7/audio-motion-avatar) has no FFI layer: its native work is reached through
+ * third-party Python wheels.  Each entry point below replaces one of those call sites (cited per function,
+ * paths relative to the reference root) and is what a ctypes binding on the reference side would bind
+ * (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - Every pointer named *_dev / documented "device" is a caller-owned HIP device pointer (a torch tensor's
+ *     data_ptr()).  The library never allocates, frees or retains device memory: scratch is a caller-provided
+ *     workspace sized by the matching *_workspace_bytes() query.
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream).  All work is enqueued
+ *     on it; no call synchronises unless documented.  No hipMalloc / hipFree / host sync on the hot path, so every
+ *     launch function may be captured into a hipGraph.
+ *   - Return value: 0 = AMAV_OK, negative = error; amav_last_error() returns a thread-local message.
+ *   - All floating-point data is IEEE fp32; indices are int32 unless stated.
+ *   - Thread-safe for distinct streams/workspaces; no mutable global state.
+ */
+#ifndef AMAV_H
+#define AMAV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AMAV_OK 0
+#define AMAV_ERR_INVALID_ARG (-1)
+#define AMAV_ERR_LAUNCH (-2)
+#define AMAV_ERR_WORKSPACE (-3)
+#define AMAV_ERR_NO_DEVICE (-4)
+
+#define AMAV_TILE 16          /* rasterizer tile edge, pixels (fixed by the algorithm being replaced) */
+#define AMAV_GAUSS_STRIDE 16  /* floats per packed Gaussian record written by amav_triplane_sample_decode */
+
+const char *amav_version(void);
+const char *amav_last_error(void);
+/* Number of visible HIP devices, or a negative error.  Does not create a context on a device. */
+int amav_device_count(void);
+
+/* One per-Gaussian (or per-point) attribute: element (f, i) lives at ptr[f * frame_stride + i * elem_stride].
+ * frame_stride = 0 broadcasts one set of Gaussians to every frame (render_multi_view, renderer.py:431-445). */
+typedef struct amav_attr {
+    const float *ptr;
+    int64_t frame_stride; /* in floats */
+    int32_t elem_stride;  /* in floats */
+    int32_t _pad;
+} amav_attr;
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Camera.  Replaces the per-frame host code of render_one (src/models/renderer.py:486-510) and
+ * getWorld2View2_torch / getProjectionMatrix_torch / focal2fov_torch (src/utils/graphic_utils.py:67-78,103-145):
+ * K [F,3,3], E [F,4,4] (row-major, device) -> viewmatrix [F,16] = E^T, projmatrix [F,16] = (K_ndc E)^T (both as
+ * the rasterizer reads them: column-major), tanfov [F,2] = (W/(2fx), H/(2fy)), campos [F,3].  No host sync.
+ */
+int amav_camera_from_intrinsics(int num_frames, const float *K_dev, const float *E_dev, int height, int width,
+                                float znear, float zfar, float *viewmatrix_dev, float *projmatrix_dev,
+                                float *tanfov_dev, float *campos_dev, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Gaussian tile rasterizer, forward, all frames of a shard in one call.
+ * Replaces GaussianRasterizer.forward of diff_gaussian_rasterization as called at src/models/renderer.py:555-566
+ * (preprocess, per-tile binning, per-tile (depth, index) sort, 16x16-tile front-to-back alpha compositing) and,
+ * with apply_activations = 1, the torch ops of renderer.py:532-547,568 that surround it.
+ */
+typedef struct amav_raster_args {
+    int32_t num_frames, num_gaussians, height, width;
+    amav_attr means3d;   /* 3 floats: world position */
+    amav_attr rotations; /* 4 floats: unit quaternion (w,x,y,z); NOT normalised here (renderer.py:333 did it) */
+    amav_attr scales;    /* 3 floats */
+    amav_attr opacities; /* 1 float  */
+    amav_attr colors;    /* 3 floats (colors_precomp; the SH branch of the reference is dead code) */
+    const float *viewmatrix; /* device [F,16] */
+    const float *projmatrix; /* device [F,16] */
+    const float *tanfov;     /* device [F,2]  */
+    float bg[3];             /* background colour (renderer.py:512-514: white by default) */
+    float scale_modifier;    /* renderer.py:522: 1.0 */
+    /* 1: scales = min(exp(s - scale_bias), scale_max), opacities = sigmoid(o - opacity_bias),
+     *    colors = clamp(c, 0, 1) are applied on load (renderer.py:532-533,547 with SCALE_BIAS 3.9, cap 0.1,
+     *    OPACITY_BIAS 0.0).  0: inputs are already activated (the op-level GaussianRasterizer contract). */
+    int32_t apply_activations;
+    float scale_bias, scale_max, opacity_bias;
+    int32_t antialiasing; /* renderer.py:529: False */
+    int32_t clamp_output; /* 1: clamp RGB to [0,1] (renderer.py:568) */
+    /* outputs (device).  out_rgba is required: [F,H,W,4] = (R,G,B,alpha = 1 - T_final), pixel-interleaved so a tile
+     * row is one 256-byte run.  out_inv_depth [F,H,W] and out_radii [F,N] (int32) may be NULL. */
+    float *out_rgba;
+    float *out_inv_depth;
+    int32_t *out_radii;
+    /* scratch */
+    void *workspace;
+    size_t workspace_bytes;
+    int64_t instance_capacity; /* max sum over frames of (tile, Gaussian) instances the workspace was sized for */
+} amav_raster_args;
+
+size_t amav_rasterize_workspace_bytes(int num_frames, int num_gaussians, int height, int width,
+                                      int64_t instance_capacity);
+int amav_rasterize_forward(const amav_raster_args *args, void *stream);
+/* Synchronises `stream`, then reports the instance count of the last forward on this workspace and whether it
+ * exceeded instance_capacity (in which case the outputs are invalid and the caller must retry with a workspace
+ * sized for *total_instances).  The only rasterizer call that waits on the device. */
+int amav_rasterize_status(const void *workspace, int64_t *total_instances, int32_t *overflow, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * SMPL-X forward + linear blend skinning for F frames.
+ * Replaces smplx.SMPLX.forward -> smplx.lbs.lbs as called at src/models/renderer.py:261-274 (no transl;
+ * use_pca=False).  Model constants are immutable device tables prepared once by the host mirror
+ * (audio-motion-avatar_amd/body_model.py) from the SMPL-X arrays:
+ *   v_template [V,3]; blend [(n_coeff + (J-1)*9), V*3]: rows 0..n_coeff-1 = shape+expression directions,
+ *   then posedirs; j_template [J,3] = J_regressor v_template; j_dirs [J*3, n_coeff] = J_regressor applied to
+ *   the shape directions; parents [J]; skin_idx / skin_w [V, skin_k]: the non-zero LBS weights of each vertex in
+ *   ascending joint order, padded with weight 0.
+ */
+typedef struct amav_body_tables {
+    int32_t num_verts, num_joints, num_coeffs, skin_k;
+    const float *v_template;
+    const float *blend;
+    const float *j_template;
+    const float *j_dirs;
+    const int32_t *parents;
+    const int32_t *skin_idx;
+    const float *skin_w;
+} amav_body_tables;
+
+size_t amav_lbs_workspace_bytes(int num_frames, const amav_body_tables *tables);
+/* full_pose [F, J*3] axis-angle (pose_mean already added), coeffs [F, n_coeff] (betas then expression).
+ * out_vertices [F,V,3]; out_joint_transforms [F,J,12] (rows of the 3x4 rest-pose-removed transforms) may be NULL. */
+int amav_lbs_forward(int num_frames, const amav_body_tables *tables, const float *full_pose_dev,
+                     const float *coeffs_dev, float *out_vertices_dev, float *out_joint_transforms_dev,
+                     void *workspace, size_t workspace_bytes, void *stream);
+
+/* Densify + subset of the posed vertices (src/models/renderer.py:276-288: pytorch3d SubdivideMeshes applied to the
+ * posed mesh once or twice, then a vertex subset) as one baked table of 4 base-vertex ids per output point:
+ *   point n = 1/2 * ( 1/2 * (v[a0] + v[b0]) + 1/2 * (v[a1] + v[b1]) ),   idx[n] = (a0, b0, a1, b1)
+ * which is the midpoint-of-midpoints order subdivision evaluates in; an original vertex repeats its id four times
+ * and a level-1 midpoint repeats its pair (halving and adding equal values is exact, so all three cases are
+ * bit-identical to the sequential subdivision). */
+int amav_points_gather(int num_frames, int num_verts, int num_points, const float *vertices_dev,
+                       const int32_t *idx_dev, float *out_points_dev, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Triplane decode: F.grid_sample x 3 planes + the five Gaussian heads + construct_gaussians
+ * (src/models/renderer.py:136,158,165-181,292-346), restructured for HBM: because the heads are linear in the
+ * sampled features and bilinear sampling is linear in the texels, each texel is projected through the head
+ * weights ONCE (amav_triplane_project: streams the [C, 3R^2] token slab exactly once, coalesced) and the points
+ * then sample the 16-channel projected planes (amav_triplane_sample_decode).
+ *
+ * head_w_plane: device [3, C, 16]: head_w_plane[p][c][o] = Wcat[o][3 + p*C + c] where Wcat [14, 3C+3] stacks the
+ * head weights in the output order below (rows 14,15 zero).  head_w_point: device [16,4]: columns 0..2 =
+ * Wcat[o][0..2] (the xyz inputs), column 3 = bias.  Output channel order o (= packed record layout):
+ *   0-2 xyz_offset, 3 opacity | 4-7 rotation (w,x,y,z) | 8-10 scaling, 11 pad | 12-14 shs, 15 pad.
+ */
+int amav_triplane_project(int num_frames, int channels, int resolution, const float *tokens_dev,
+                          int64_t tokens_frame_stride, const float *head_w_plane_dev, float *out_proj_dev,
+                          void *stream);
+/* points [F,N,3]; transl [F,3] or NULL; proj [F,3,R,R,16] from amav_triplane_project.
+ * out_gaussians [F,N,16] packed records: xyz = p + offset + transl, opacity (raw logit) | rot (normalised) |
+ * scale (raw), 0 | color = sigmoid(shs), 0.   (renderer.py:333-344) */
+int amav_triplane_sample_decode(int num_frames, int num_points, int resolution, const float *proj_dev,
+                                const float *points_dev, const float *transl_dev, float radius,
+                                const float *head_w_point_dev, float *out_gaussians_dev, void *stream);
+/* Plain Renderer.sample_from_triplane (renderer.py:292-317): element (f,p,c,h,w) of the planes lives at
+ * planes[f*frame_stride + p*plane_stride + c*chan_stride + h*R + w] (so both the [F,3,C,R,R] tensor and the
+ * [F,C,(3 R R)] token layout are addressable); points [F,N,3] -> features [F,N,3C] in (plane, channel) order. */
+int amav_triplane_sample_features(int num_frames, int num_points, int channels, int resolution,
+                                  const float *planes_dev, int64_t frame_stride, int64_t plane_stride,
+                                  int64_t chan_stride, const float *points_dev, float radius,
+                                  float *out_features_dev, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Self-attention of the audio transformer (diffusers Attention -> F.scaled_dot_product_attention as reached from
+ * src/models/transformers.py:329-336): softmax(Q K^T * scale) V, fp32 in/out, no mask, on MFMA
+ * (v_mfma_f32_32x32x2_f32, exact fp32 products).  q,k,v,out: [B, S, H*D] with row stride `row_stride` floats
+ * (so a fused QKV projection output can be passed without a copy); D must be 64.
+ */
+int amav_selfattn_forward(int batch, int seq_len, int heads, int head_dim, const float *q_dev, const float *k_dev,
+                          const float *v_dev, int64_t row_stride, float *out_dev, int64_t out_row_stride,
+                          float scale, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AMAV_H */

@@ -1,0 +1,62 @@
+"""Triplane sampling, Gaussian heads and Renderer.forward, restated on CPU.
+
+Follows src/models/renderer.py:73-204 (Renderer.forward), :292-317 (sample_from_triplane, which calls
+torch's own F.grid_sample), :165-171 (five linear heads) and :319-346 (construct_gaussians).
+Parameters are passed as a state-dict-like mapping with the reference's names
+(`gaussian_decoder.xyz_layer.weight`, ...; renderer.py:51-55).  Test infrastructure only (oracle/__init__.py).
+"""
+import einops
+import torch
+import torch.nn.functional as F
+
+HEADS = ("xyz_layer", "rotation_layer", "scaling_layer", "opacity_layer", "shs_layer")
+
+
+def tokens_to_planes(triplane_tokens, resolution):
+    """renderer.py:85-91: [B,T,C,(Np Hp Wp)] -> [(B T),3,C,R,R]."""
+    return einops.rearrange(triplane_tokens, "B T Ct (Np Hp Wp) -> (B T) Np Ct Hp Wp", Np=3, Hp=resolution,
+                            Wp=resolution)
+
+
+def sample_from_triplane(triplane_features, points, radius):
+    """renderer.py:292-317.  triplane_features [B,3,C,R,R], points [B,N,3] -> [B,N,3C]."""
+    batched = points.ndim == 3
+    if not batched:
+        triplane_features = triplane_features[None, ...]
+        points = points[None, ...]
+    positions = torch.clamp(points / radius, -1, 1)
+    indices2D = torch.stack((positions[..., [0, 1]], positions[..., [0, 2]], positions[..., [1, 2]]), dim=-3)
+    out = F.grid_sample(
+        einops.rearrange(triplane_features, "B Np Cp Hp Wp -> (B Np) Cp Hp Wp", Np=3),
+        einops.rearrange(indices2D, "B Np N Nd -> (B Np) () N Nd", Np=3),
+        align_corners=False,
+        mode="bilinear",
+    )
+    out = einops.rearrange(out, "(B Np) Cp () N -> B N (Np Cp)", Np=3)
+    if not batched:
+        out = out.squeeze(0)
+    return out
+
+
+def gaussian_heads(params, decoder_input, prefix="gaussian_decoder."):
+    """renderer.py:167-171."""
+    lin = lambda name: F.linear(decoder_input, params[prefix + name + ".weight"], params[prefix + name + ".bias"])
+    return dict(xyz_offset=lin("xyz_layer"), rotation=lin("rotation_layer"), scaling=lin("scaling_layer"),
+                opacity=lin("opacity_layer"), shs=lin("shs_layer"))
+
+
+def construct_gaussians(gaussian_params, points, transl):
+    """renderer.py:319-346.  transl [F,3]."""
+    rotation = F.normalize(gaussian_params["rotation"], dim=-1)
+    color = torch.sigmoid(gaussian_params["shs"])
+    return dict(xyz=points + gaussian_params["xyz_offset"] + transl.reshape(-1, 1, 3),
+                scale=gaussian_params["scaling"], rot=rotation, opacity=gaussian_params["opacity"], color=color,
+                shs=color)
+
+
+def decode_gaussians(params, triplane_features, points, transl, radius):
+    """renderer.py:136-181 with the point refiner bypassed (offset == 0: an untrained refiner's last layer is
+    zero-initialised, renderer.py:46-47; PTv3 is a SURVEY section 8(f) next-row)."""
+    feats = sample_from_triplane(triplane_features, points, radius)
+    decoder_input = torch.cat([points, feats], dim=-1)
+    return construct_gaussians(gaussian_heads(params, decoder_input), points, transl)
