@@ -35,6 +35,8 @@ class RasterArgs(ctypes.Structure):
         ("out_rgba", ctypes.c_void_p), ("out_inv_depth", ctypes.c_void_p), ("out_radii", ctypes.c_void_p),
         ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t),
         ("instance_capacity", ctypes.c_int64),
+        ("profile_start_event", ctypes.c_void_p), ("profile_stop_event", ctypes.c_void_p),
+        ("debug_stamps", ctypes.c_void_p),
     ]
 
 
@@ -53,6 +55,10 @@ SIGNATURES = {
     "amav_version": (ctypes.c_char_p, []),
     "amav_last_error": (ctypes.c_char_p, []),
     "amav_device_count": (ctypes.c_int, []),
+    "amav_event_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p)]),
+    "amav_event_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "amav_event_record": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "amav_event_elapsed_ms": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]),
     "amav_camera_from_intrinsics": (ctypes.c_int, [ctypes.c_int, c_float_p, c_float_p, ctypes.c_int, ctypes.c_int,
                                                    ctypes.c_float, ctypes.c_float, c_float_p, c_float_p, c_float_p,
                                                    c_float_p, ctypes.c_void_p]),
@@ -60,7 +66,9 @@ SIGNATURES = {
                                                          ctypes.c_int64]),
     "amav_rasterize_forward": (ctypes.c_int, [ctypes.POINTER(RasterArgs), ctypes.c_void_p]),
     "amav_rasterize_status": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64),
-                                             ctypes.POINTER(ctypes.c_int32), ctypes.c_void_p]),
+                                             ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int32),
+                                             ctypes.c_void_p]),
+    "amav_frames_to_rgb8": (ctypes.c_int, [ctypes.c_int64, c_float_p, ctypes.c_void_p, ctypes.c_void_p]),
     "amav_lbs_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.POINTER(BodyTables)]),
     "amav_lbs_forward": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(BodyTables), c_float_p, c_float_p, c_float_p,
                                         c_float_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),

@@ -1,0 +1,86 @@
+"""Configuration objects with the reference's field names.
+
+The reference flattens its YAML tree into one namespace (src/configs/config_loader.py:190-234) and hands it to
+`Renderer(cfg)` / `SMPLXDecoder(cfg)`, while `AudioTriplaneNet(cfg)` reads `cfg.model.triplane_audio_net.*`
+(src/models/triplane_audio_net.py:94).  Any object with these attributes works (an OmegaConf node from the
+reference included); these dataclasses are the Lightning/omegaconf-free way to build one.  Defaults are the
+reference's YAML values (src/configs/model/*.yaml, src/configs/datasets/ted_speech.yaml) except for the two
+switches SURVEY.md section 8(f) defers: `upsample_triplane` and the PTv3 point refiner are off.
+"""
+from dataclasses import dataclass, field
+from types import SimpleNamespace
+from typing import Optional, Tuple
+
+import yaml
+
+
+@dataclass
+class RendererConfig:
+    # src/configs/model/triplane_net.yaml:3-16
+    triplane_resolution: int = 32
+    triplane_feature_dim: int = 256
+    radius: float = 1.4
+    smplx_model_path: Optional[str] = None
+    smpl_token_len: int = 80
+    smpl_token_dim: int = 256
+    # src/configs/datasets/ted_speech.yaml:14-17
+    flat_hand_mean: bool = True
+    num_expression_coeffs: int = 10
+    image_size: Tuple[int, int] = (512, 512)  # (H, W); BASELINE configs use 512x512
+    # src/configs/model/renderer.yaml:10-22
+    upsample_triplane: bool = False   # reference default true: SURVEY 8(f) next-row
+    num_upsample_blocks: int = 4
+    densify_smplx_verts: bool = True
+    subdivide_steps: int = 0          # 0 -> 10 000 sampled vertices (BASELINE), reference default 2 -> 30 000
+    predict_smplx_params: bool = True
+    no_point_refiner: bool = True     # reference default false (PTv3): SURVEY 8(f) next-row
+    use_gaussian_splatting: bool = True
+    gaussian_feature_dim: int = 256
+    rgb: bool = True
+    sh_degree: int = 3
+    device: str = "cuda"
+    # deterministic-inference additions (SURVEY.md "Hard parts"): the reference re-draws the vertex subset with
+    # torch.randperm on every forward (renderer.py:287); here it is drawn once from this seed.
+    subset_seed: int = 42
+    body_seed: int = 42               # seed of the synthetic body used when smplx_model_path is absent
+
+
+@dataclass
+class AudioNetConfig:
+    # src/configs/model/triplane_audio_net.yaml:3-14
+    triplane_input_frames: int = 2
+    triplane_output_frames: int = 6
+    triplane_feature_dim: int = 256
+    triplane_resolution: int = 32
+    smpl_token_len: int = 80
+    smpl_token_dim: int = 256
+    transformer_layers: int = 8
+    transformer_head_dim: int = 64
+    transformer_num_heads: int = 8
+    audio_feature_dim: int = 768
+
+
+@dataclass
+class ModelConfig:
+    """`cfg` as AudioTriplaneNet expects it: cfg.model.triplane_audio_net.* (triplane_audio_net.py:94)."""
+    triplane_audio_net: AudioNetConfig = field(default_factory=AudioNetConfig)
+    renderer: RendererConfig = field(default_factory=RendererConfig)
+
+    @property
+    def model(self):
+        return self
+
+
+def load_yaml(path: str) -> SimpleNamespace:
+    """Plain YAML -> nested attribute namespace (PyYAML safe loader; no `${...}` interpolation, no eval)."""
+    with open(path) as f:
+        data = yaml.safe_load(f)
+
+    def ns(x):
+        if isinstance(x, dict):
+            return SimpleNamespace(**{k: ns(v) for k, v in x.items()})
+        if isinstance(x, list):
+            return [ns(v) for v in x]
+        return x
+
+    return ns(data)

@@ -70,3 +70,33 @@ extern "C" int amav_camera_from_intrinsics(int F, const float *K, const float *E
                                                                              znear, zfar, view, proj, tanfov, campos);
     return check_launch("amav_camera_from_intrinsics");
 }
+
+extern "C" int amav_event_create(void **event) {
+    AMAV_REQUIRE(event != nullptr, "amav_event_create: NULL");
+    hipEvent_t e;
+    hipError_t rc = hipEventCreate(&e);
+    if (rc != hipSuccess) return fail(AMAV_ERR_LAUNCH, "hipEventCreate: %s", hipGetErrorString(rc));
+    *event = e;
+    return AMAV_OK;
+}
+
+extern "C" int amav_event_destroy(void *event) {
+    if (event && hipEventDestroy(static_cast<hipEvent_t>(event)) != hipSuccess)
+        return fail(AMAV_ERR_LAUNCH, "hipEventDestroy failed");
+    return AMAV_OK;
+}
+
+extern "C" int amav_event_record(void *event, void *stream) {
+    AMAV_REQUIRE(event != nullptr, "amav_event_record: NULL event");
+    hipError_t rc = hipEventRecord(static_cast<hipEvent_t>(event), static_cast<hipStream_t>(stream));
+    if (rc != hipSuccess) return fail(AMAV_ERR_LAUNCH, "hipEventRecord: %s", hipGetErrorString(rc));
+    return AMAV_OK;
+}
+
+extern "C" int amav_event_elapsed_ms(void *start, void *stop, float *ms) {
+    AMAV_REQUIRE(start && stop && ms, "amav_event_elapsed_ms: NULL");
+    hipError_t rc = hipEventSynchronize(static_cast<hipEvent_t>(stop));
+    if (rc == hipSuccess) rc = hipEventElapsedTime(ms, static_cast<hipEvent_t>(start), static_cast<hipEvent_t>(stop));
+    if (rc != hipSuccess) return fail(AMAV_ERR_LAUNCH, "hipEventElapsedTime: %s", hipGetErrorString(rc));
+    return AMAV_OK;
+}

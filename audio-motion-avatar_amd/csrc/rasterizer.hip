@@ -3,49 +3,68 @@
 // Replaces diff_gaussian_rasterization's GaussianRasterizer.forward as the reference calls it
 // (src/models/renderer.py:555-566) plus the activations around it (renderer.py:532-547,568).  The algorithm being
 // replaced fixes the numbers: 16x16 tiles, (tile, depth, index) order, the 0.99 / 1/255 /
-// 1e-4 blend thresholds.  Everything else is laid out for CDNA4:
+// 1e-4 blend thresholds.  Everything else is laid out for CDNA4 (three launches per shard instead of upstream's
+// six launches + two CUB passes + a host sync per frame):
 //
-//   preprocess  1 thread / (frame, Gaussian): cull, project, conic, 3-sigma tile rectangle; counts instances per
-//               tile with integer atomics (L2-resident counters, ~3 per Gaussian).
-//   scan        per-frame block scan of the tile counters, then one block scans the frame totals: instance
-//               ranges for every (frame, tile) without a host round trip (upstream syncs to read the total).
-//   scatter     every visible Gaussian drops (depth_bits << 32 | index) keys into its tiles' ranges.
-//   sort        ONE WAVEFRONT PER TILE sorts its range in LDS with a normalised bitonic network (all comparators
-//               ascending, so ragged lengths need no padding); keys are unique, so the result equals upstream's
-//               stable radix sort by (tile, depth).  Oversized ranges go to a persistent big-tile kernel.
-//   render      ONE WAVEFRONT PER TILE, 4 pixels per lane (same column, rows 4 apart): the tile's Gaussians are
-//               staged 64 at a time in LDS and read back as wave-uniform broadcasts; early-out by __all();
-//               output is pixel-interleaved RGBA so each store instruction writes four full 256-byte tile rows.
-//               Block ids are remapped so that one XCD's L2 sees whole frames (the per-frame Gaussian records
-//               are fetched into one L2, not eight).
+//   bin_kernel     ONE 1024-THREAD BLOCK PER FRAME does preprocess, per-tile counting, the scan and the key scatter
+//                  for its frame, with the tile counters in LDS.  Device-scope atomics on scattered addresses run at
+//                  the memory side on MI355X (the eight XCD L2s are not coherent; measured 0.43 ms per 8.4 M adds);
+//                  LDS atomics do not.  Frames own fixed instance regions, so there is no cross-frame scan and no
+//                  host round trip (upstream syncs to read the instance count).
+//   sort_big       persistent blocks sort the rare tile lists longer than 512 in LDS (<= 16 K keys) or in place.
+//   render_kernel  ONE WAVEFRONT PER TILE: loads its keys, sorts them in its LDS slice (rank sort <= 256 keys,
+//                  normalised bitonic <= 512; keys are unique, so the order equals upstream's stable radix sort by
+//                  (tile, depth)), then blends 4 pixels per lane -- one in each 8x8 quadrant of the tile.  Gaussians
+//                  are staged 64 at a time through LDS; the staging lane tests the Gaussian's exact alpha >= 1/255
+//                  bounding box against the four quadrants, drops Gaussians that cannot touch the tile (ballot +
+//                  mbcnt compaction) and records a 4-bit quadrant mask, so the wave only evaluates quadrants the
+//                  Gaussian can reach (wave-uniform branches; skipped evaluations are ones the reference would
+//                  reject with alpha < 1/255, so the output is unchanged).  Early-out by __all(); the state of a
+//                  finished pixel is the sign of its transmittance.  Output is pixel-interleaved RGBA, so every
+//                  store instruction writes eight full 128-byte lines.  Block ids are remapped so that one XCD's
+//                  L2 sees whole frames.
+#include <cstdlib>
+
 #include "amav_common.h"
 
 namespace amav {
 namespace raster {
 
 constexpr int kTile = AMAV_TILE;
-constexpr int kSmallCap = 1024;   // keys one wave sorts in its LDS slice (8 KiB)
-constexpr int kBigLdsCap = 16384; // keys a 1024-thread block sorts in LDS (128 KiB)
+constexpr int kRankCap = 256;      // keys a wave rank-sorts (4 per lane)
+constexpr int kSortCap = 512;      // keys a wave sorts in its LDS slice (4 KiB); longer lists go to sort_big
+constexpr int kBigLdsCap = 16384;  // keys a 1024-thread block sorts in LDS (128 KiB)
 constexpr int kBigBlocks = 256;
+constexpr float kLog2e = 1.4426950408889634f;
+
+constexpr int kQueues = 8;    // one work queue per XCD (frame f feeds queue f % 8, so an XCD's L2 sees whole frames)
+constexpr int kBuckets = 17;  // list-length classes: bucket 0 = longer than 512, then 481..512, ..., 1..32
+
+__host__ __device__ inline int bucket_of(int n) { return n > 512 ? 0 : 16 - (n - 1) / 32; }
 
 struct Status {
-    long long total;
-    int overflow;
-    int big_count;
+    long long total;      // sum over frames of (tile, Gaussian) instances
+    long long max_frame;  // largest per-frame instance count
+    int overflow;         // some frame exceeded its region
+    int big_count;        // tiles queued for sort_big
+    // work lists of the blend kernel: per XCD queue, bucketed by list length (bucket 0 = longest)
+    int qcount[kQueues][kBuckets];
+    int nempty;           // tiles without Gaussians (background fill)
 };
 
 struct Buffers {
-    float4 *geom;              // [F*N][3]: {x, y, conA, conB} {conC, opacity, r, g} {b, 1/depth, -, -}
+    float4 *geom;              // [F*N][3]: {x, y, conA', conB'} {conC', opacity, r, g} {b, 1/depth, hx, hy}
     uint4 *rectd;              // [F*N]: {rx0 | ry0 << 16, rx1 | ry1 << 16, depth bits, radius}
-    int *tile_count;           // [F*T]
     int *tile_off;             // [F*(T+1)] exclusive scan within the frame
-    long long *frame_total;    // [F]
-    long long *frame_base;     // [F]
-    unsigned long long *keys;  // [capacity]
-    unsigned *sorted;          // [capacity] Gaussian indices in blend order
-    int *big_list;             // [F*T] (frame * T + tile) of ranges longer than kSmallCap
+    unsigned long long *keys;  // [F * cap_per_frame]
+    unsigned *sorted;          // [F * cap_per_frame] blend order of the big tiles only
+    int *big_list;             // [F*T] (frame * T + tile) of lists longer than kSortCap
+    int *queue;                // [kQueues][kBuckets][qcap] (frame * T + tile) of non-empty tiles
+    int *empty_list;           // [F*T] (frame * T + tile) of empty tiles
     Status *status;
 };
+
+static inline size_t queue_capacity(int F, int T) { return (size_t)((F + kQueues - 1) / kQueues) * T; }
 
 static Buffers carve(void *ws, int F, int N, int T, long long cap, size_t *bytes) {
     Carver c(ws);
@@ -53,13 +72,12 @@ static Buffers carve(void *ws, int F, int N, int T, long long cap, size_t *bytes
     b.status = c.take<Status>(1);
     b.geom = c.take<float4>((size_t)F * N * 3);
     b.rectd = c.take<uint4>((size_t)F * N);
-    b.tile_count = c.take<int>((size_t)F * T);
     b.tile_off = c.take<int>((size_t)F * (T + 1));
-    b.frame_total = c.take<long long>(F);
-    b.frame_base = c.take<long long>(F);
     b.keys = c.take<unsigned long long>((size_t)cap);
     b.sorted = c.take<unsigned>((size_t)cap);
     b.big_list = c.take<int>((size_t)F * T);
+    b.queue = c.take<int>((size_t)kQueues * kBuckets * queue_capacity(F, T));
+    b.empty_list = c.take<int>((size_t)F * T);
     if (bytes) *bytes = c.total();
     return b;
 }
@@ -76,7 +94,10 @@ struct Params {
     float *out_rgba;
     float *out_inv_depth;
     int *out_radii;
-    long long capacity;
+    long long cap_per_frame;
+    int qcap;  // entries per work queue
+    unsigned long long *stamps;  // diagnostic: [F*T][6] s_memtime stamps per tile wave, or NULL
+    int debug_flags;  // AMAV_RASTER_DEBUG (timing ablations only: 1 = no sort, 2 = no blend, 4 = no stores)
     Buffers buf;
 };
 
@@ -92,137 +113,138 @@ __device__ __forceinline__ void wave_sync() {
 }
 
 // ---------------------------------------------------------------------------------------------------- preprocess
-__global__ __launch_bounds__(256) void preprocess_kernel(Params p) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int f = blockIdx.y;
-    if (i >= p.N) return;
+// One Gaussian of frame f.  Contraction is off and the operation order is the oracle's (oracle/raster_ref.c): +, *,
+// /, sqrt are correctly rounded on both sides, so depth keys, radii and tile rectangles -- the decisions that move
+// whole Gaussians between tiles or swap their blend order -- come out bit-identical to the CPU restatement.
+__device__ __forceinline__ uint4 preprocess_one(const Params &p, int f, int i, const float *vm, const float *pm,
+                                                float tanx, float tany) {
+#pragma clang fp contract(off)
     const size_t gi = (size_t)f * p.N + i;
     uint4 rd = make_uint4(0u, 0u, 0u, 0u);
-    int radius_out = 0;
-
-    const float *vm = p.view + f * 16;
-    const float *pm = p.proj + f * 16;
     const float *m = at(p.means3d, f, i);
     const float px3 = m[0], py3 = m[1], pz3 = m[2];
     const float vx = vm[0] * px3 + vm[4] * py3 + vm[8] * pz3 + vm[12];
     const float vy = vm[1] * px3 + vm[5] * py3 + vm[9] * pz3 + vm[13];
     const float vz = vm[2] * px3 + vm[6] * py3 + vm[10] * pz3 + vm[14];
-    if (vz > 0.2f) {
-        const float hx = pm[0] * px3 + pm[4] * py3 + pm[8] * pz3 + pm[12];
-        const float hy = pm[1] * px3 + pm[5] * py3 + pm[9] * pz3 + pm[13];
-        const float hw = pm[3] * px3 + pm[7] * py3 + pm[11] * pz3 + pm[15];
-        const float pw = 1.0f / (hw + 0.0000001f);
-        const float ppx = hx * pw, ppy = hy * pw;
+    if (!(vz > 0.2f)) return rd;
+    const float hx_ = pm[0] * px3 + pm[4] * py3 + pm[8] * pz3 + pm[12];
+    const float hy_ = pm[1] * px3 + pm[5] * py3 + pm[9] * pz3 + pm[13];
+    const float hw = pm[3] * px3 + pm[7] * py3 + pm[11] * pz3 + pm[15];
+    const float pw = 1.0f / (hw + 0.0000001f);
+    const float ppx = hx_ * pw, ppy = hy_ * pw;
 
-        const float *q = at(p.rotations, f, i);
-        const float r = q[0], x = q[1], y = q[2], z = q[3];
-        const float *sc = at(p.scales, f, i);
-        float s0 = sc[0], s1 = sc[1], s2 = sc[2];
-        float opacity = at(p.opacities, f, i)[0];
-        const float *cl = at(p.colors, f, i);
-        float c0 = cl[0], c1 = cl[1], c2 = cl[2];
-        if (p.apply_activations) {
-            s0 = fminf(expf(s0 - p.scale_bias), p.scale_max);
-            s1 = fminf(expf(s1 - p.scale_bias), p.scale_max);
-            s2 = fminf(expf(s2 - p.scale_bias), p.scale_max);
-            opacity = 1.0f / (1.0f + expf(-(opacity - p.opacity_bias)));
-            c0 = fminf(fmaxf(c0, 0.0f), 1.0f);
-            c1 = fminf(fmaxf(c1, 0.0f), 1.0f);
-            c2 = fminf(fmaxf(c2, 0.0f), 1.0f);
-        }
-        s0 *= p.scale_modifier;
-        s1 *= p.scale_modifier;
-        s2 *= p.scale_modifier;
-
-        // Sigma3D = R diag(s)^2 R^T
-        const float R00 = 1.f - 2.f * (y * y + z * z), R01 = 2.f * (x * y - r * z), R02 = 2.f * (x * z + r * y);
-        const float R10 = 2.f * (x * y + r * z), R11 = 1.f - 2.f * (x * x + z * z), R12 = 2.f * (y * z - r * x);
-        const float R20 = 2.f * (x * z - r * y), R21 = 2.f * (y * z + r * x), R22 = 1.f - 2.f * (x * x + y * y);
-        const float M00 = s0 * R00, M01 = s0 * R10, M02 = s0 * R20;
-        const float M10 = s1 * R01, M11 = s1 * R11, M12 = s1 * R21;
-        const float M20 = s2 * R02, M21 = s2 * R12, M22 = s2 * R22;
-        const float S00 = M00 * M00 + M10 * M10 + M20 * M20;
-        const float S01 = M00 * M01 + M10 * M11 + M20 * M21;
-        const float S02 = M00 * M02 + M10 * M12 + M20 * M22;
-        const float S11 = M01 * M01 + M11 * M11 + M21 * M21;
-        const float S12 = M01 * M02 + M11 * M12 + M21 * M22;
-        const float S22 = M02 * M02 + M12 * M12 + M22 * M22;
-
-        // EWA splat: cov2D = (J Wv) Sigma (J Wv)^T
-        const float tanx = p.tanfov[2 * f], tany = p.tanfov[2 * f + 1];
-        const float focal_x = (float)p.W / (2.0f * tanx), focal_y = (float)p.H / (2.0f * tany);
-        const float limx = 1.3f * tanx, limy = 1.3f * tany;
-        const float tz = vz;
-        const float tx = fminf(limx, fmaxf(-limx, vx / tz)) * tz;
-        const float ty = fminf(limy, fmaxf(-limy, vy / tz)) * tz;
-        const float J00 = focal_x / tz, J02 = -(focal_x * tx) / (tz * tz);
-        const float J11 = focal_y / tz, J12 = -(focal_y * ty) / (tz * tz);
-        float T0[3], T1[3];
-#pragma unroll
-        for (int b = 0; b < 3; ++b) {
-            T0[b] = J00 * vm[b * 4 + 0] + J02 * vm[b * 4 + 2];
-            T1[b] = J11 * vm[b * 4 + 1] + J12 * vm[b * 4 + 2];
-        }
-        const float U00 = S00 * T0[0] + S01 * T0[1] + S02 * T0[2];
-        const float U01 = S01 * T0[0] + S11 * T0[1] + S12 * T0[2];
-        const float U02 = S02 * T0[0] + S12 * T0[1] + S22 * T0[2];
-        const float U10 = S00 * T1[0] + S01 * T1[1] + S02 * T1[2];
-        const float U11 = S01 * T1[0] + S11 * T1[1] + S12 * T1[2];
-        const float U12 = S02 * T1[0] + S12 * T1[1] + S22 * T1[2];
-        float ca = T0[0] * U00 + T0[1] * U01 + T0[2] * U02;
-        const float cb = T0[0] * U10 + T0[1] * U11 + T0[2] * U12;
-        float cc = T1[0] * U10 + T1[1] * U11 + T1[2] * U12;
-
-        const float det_cov = ca * cc - cb * cb;
-        ca += 0.3f;
-        cc += 0.3f;
-        const float det = ca * cc - cb * cb;
-        float h_scale = 1.0f;
-        if (p.antialiasing) h_scale = sqrtf(fmaxf(0.000025f, det_cov / det));
-        if (det != 0.0f) {
-            const float det_inv = 1.0f / det;
-            const float mid = 0.5f * (ca + cc);
-            const float root = sqrtf(fmaxf(0.1f, mid * mid - det));
-            const float my_radius = ceilf(3.0f * sqrtf(fmaxf(mid + root, mid - root)));
-            const float pix_x = ((ppx + 1.0f) * (float)p.W - 1.0f) * 0.5f;
-            const float pix_y = ((ppy + 1.0f) * (float)p.H - 1.0f) * 0.5f;
-            const int rx0 = min(p.gx, max(0, (int)((pix_x - my_radius) / (float)kTile)));
-            const int ry0 = min(p.gy, max(0, (int)((pix_y - my_radius) / (float)kTile)));
-            const int rx1 = min(p.gx, max(0, (int)((pix_x + my_radius + (float)(kTile - 1)) / (float)kTile)));
-            const int ry1 = min(p.gy, max(0, (int)((pix_y + my_radius + (float)(kTile - 1)) / (float)kTile)));
-            if ((rx1 - rx0) * (ry1 - ry0) > 0) {
-                radius_out = (int)my_radius;
-                rd = make_uint4((unsigned)rx0 | ((unsigned)ry0 << 16), (unsigned)rx1 | ((unsigned)ry1 << 16),
-                                __float_as_uint(vz), (unsigned)radius_out);
-                float4 *g = p.buf.geom + gi * 3;
-                g[0] = make_float4(pix_x, pix_y, cc * det_inv, -cb * det_inv);
-                g[1] = make_float4(ca * det_inv, opacity * h_scale, c0, c1);
-                g[2] = make_float4(c2, 1.0f / vz, 0.f, 0.f);
-                int *cnt = p.buf.tile_count + (size_t)f * p.T;
-                for (int ty_ = ry0; ty_ < ry1; ++ty_)
-                    for (int tx_ = rx0; tx_ < rx1; ++tx_) atomicAdd(cnt + ty_ * p.gx + tx_, 1);
-            }
-        }
+    const float *q = at(p.rotations, f, i);
+    const float r = q[0], x = q[1], y = q[2], z = q[3];
+    const float *sc = at(p.scales, f, i);
+    float s0 = sc[0], s1 = sc[1], s2 = sc[2];
+    float opacity = at(p.opacities, f, i)[0];
+    const float *cl = at(p.colors, f, i);
+    float c0 = cl[0], c1 = cl[1], c2 = cl[2];
+    if (p.apply_activations) {
+        s0 = fminf(expf(s0 - p.scale_bias), p.scale_max);
+        s1 = fminf(expf(s1 - p.scale_bias), p.scale_max);
+        s2 = fminf(expf(s2 - p.scale_bias), p.scale_max);
+        opacity = 1.0f / (1.0f + expf(-(opacity - p.opacity_bias)));
+        c0 = fminf(fmaxf(c0, 0.0f), 1.0f);
+        c1 = fminf(fmaxf(c1, 0.0f), 1.0f);
+        c2 = fminf(fmaxf(c2, 0.0f), 1.0f);
     }
-    p.buf.rectd[gi] = rd;
-    if (p.out_radii) p.out_radii[gi] = radius_out;
+    s0 *= p.scale_modifier;
+    s1 *= p.scale_modifier;
+    s2 *= p.scale_modifier;
+
+    // Sigma3D = R diag(s)^2 R^T
+    const float R00 = 1.f - 2.f * (y * y + z * z), R01 = 2.f * (x * y - r * z), R02 = 2.f * (x * z + r * y);
+    const float R10 = 2.f * (x * y + r * z), R11 = 1.f - 2.f * (x * x + z * z), R12 = 2.f * (y * z - r * x);
+    const float R20 = 2.f * (x * z - r * y), R21 = 2.f * (y * z + r * x), R22 = 1.f - 2.f * (x * x + y * y);
+    const float M00 = s0 * R00, M01 = s0 * R10, M02 = s0 * R20;
+    const float M10 = s1 * R01, M11 = s1 * R11, M12 = s1 * R21;
+    const float M20 = s2 * R02, M21 = s2 * R12, M22 = s2 * R22;
+    const float S00 = M00 * M00 + M10 * M10 + M20 * M20;
+    const float S01 = M00 * M01 + M10 * M11 + M20 * M21;
+    const float S02 = M00 * M02 + M10 * M12 + M20 * M22;
+    const float S11 = M01 * M01 + M11 * M11 + M21 * M21;
+    const float S12 = M01 * M02 + M11 * M12 + M21 * M22;
+    const float S22 = M02 * M02 + M12 * M12 + M22 * M22;
+
+    // EWA splat: cov2D = (J Wv) Sigma (J Wv)^T
+    const float focal_x = (float)p.W / (2.0f * tanx), focal_y = (float)p.H / (2.0f * tany);
+    const float limx = 1.3f * tanx, limy = 1.3f * tany;
+    const float tz = vz;
+    const float tx = fminf(limx, fmaxf(-limx, vx / tz)) * tz;
+    const float ty = fminf(limy, fmaxf(-limy, vy / tz)) * tz;
+    const float J00 = focal_x / tz, J02 = -(focal_x * tx) / (tz * tz);
+    const float J11 = focal_y / tz, J12 = -(focal_y * ty) / (tz * tz);
+    float T0[3], T1[3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        T0[b] = J00 * vm[b * 4 + 0] + J02 * vm[b * 4 + 2];
+        T1[b] = J11 * vm[b * 4 + 1] + J12 * vm[b * 4 + 2];
+    }
+    const float U00 = S00 * T0[0] + S01 * T0[1] + S02 * T0[2];
+    const float U01 = S01 * T0[0] + S11 * T0[1] + S12 * T0[2];
+    const float U02 = S02 * T0[0] + S12 * T0[1] + S22 * T0[2];
+    const float U10 = S00 * T1[0] + S01 * T1[1] + S02 * T1[2];
+    const float U11 = S01 * T1[0] + S11 * T1[1] + S12 * T1[2];
+    const float U12 = S02 * T1[0] + S12 * T1[1] + S22 * T1[2];
+    float ca = T0[0] * U00 + T0[1] * U01 + T0[2] * U02;
+    const float cb = T0[0] * U10 + T0[1] * U11 + T0[2] * U12;
+    float cc = T1[0] * U10 + T1[1] * U11 + T1[2] * U12;
+
+    const float det_cov = ca * cc - cb * cb;
+    ca += 0.3f;
+    cc += 0.3f;
+    const float det = ca * cc - cb * cb;
+    float h_scale = 1.0f;
+    if (p.antialiasing) h_scale = sqrtf(fmaxf(0.000025f, det_cov / det));
+    if (det == 0.0f) return rd;
+    const float det_inv = 1.0f / det;
+    const float mid = 0.5f * (ca + cc);
+    const float root = sqrtf(fmaxf(0.1f, mid * mid - det));
+    const float my_radius = ceilf(3.0f * sqrtf(fmaxf(mid + root, mid - root)));
+    const float pix_x = ((ppx + 1.0f) * (float)p.W - 1.0f) * 0.5f;
+    const float pix_y = ((ppy + 1.0f) * (float)p.H - 1.0f) * 0.5f;
+    const int rx0 = min(p.gx, max(0, (int)((pix_x - my_radius) / (float)kTile)));
+    const int ry0 = min(p.gy, max(0, (int)((pix_y - my_radius) / (float)kTile)));
+    const int rx1 = min(p.gx, max(0, (int)((pix_x + my_radius + (float)(kTile - 1)) / (float)kTile)));
+    const int ry1 = min(p.gy, max(0, (int)((pix_y + my_radius + (float)(kTile - 1)) / (float)kTile)));
+    if ((rx1 - rx0) * (ry1 - ry0) <= 0) return rd;
+
+    const float op = opacity * h_scale;
+    // Exact support of the blend: alpha = op * exp(power) >= 1/255  <=>  d^T Q d <= 2 ln(255 op), whose axis-aligned
+    // half extents are sqrt(2 ln(255 op) * cov_xx|yy).  Padded (1e-3 relative + 0.01 px), so a pixel outside the box
+    // is rejected by the reference with a margin far above rounding; render_kernel uses the box to skip quadrants.
+    const float tau = 2.0f * logf(255.0f * op);
+    float bx = -1e30f, by = -1e30f;
+    if (tau > 0.0f) {
+        bx = sqrtf(tau * ca) * 1.001f + 0.01f;
+        by = sqrtf(tau * cc) * 1.001f + 0.01f;
+    }
+    rd = make_uint4((unsigned)rx0 | ((unsigned)ry0 << 16), (unsigned)rx1 | ((unsigned)ry1 << 16), __float_as_uint(vz),
+                    (unsigned)(int)my_radius);
+    float4 *g = p.buf.geom + gi * 3;
+    // the conic is stored pre-multiplied by log2(e): the blend evaluates exp2 directly
+    g[0] = make_float4(pix_x, pix_y, (cc * det_inv) * kLog2e, (-cb * det_inv) * kLog2e);
+    g[1] = make_float4((ca * det_inv) * kLog2e, op, c0, c1);
+    g[2] = make_float4(c2, 1.0f / vz, bx, by);
+    return rd;
 }
 
-// ---------------------------------------------------------------------------------------------------------- scans
-// Exclusive scan of v over the block (256 threads); returns the prefix of this thread, *total = block sum.
-__device__ __forceinline__ long long block_exclusive_scan(long long v, long long *lds_wave, long long *total) {
+// ------------------------------------------------------------------------------------------------------------ bin
+// Block-wide exclusive scan helper (blockDim.x = 1024 = 16 waves).
+__device__ __forceinline__ int block_exclusive_scan(int v, int *lds_wave, int *total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    long long incl = v;
+    int incl = v;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-        long long o = __shfl_up(incl, d, 64);
+        const int o = __shfl_up(incl, d, 64);
         if (lane >= d) incl += o;
     }
     if (lane == 63) lds_wave[wave] = incl;
     __syncthreads();
-    long long wave_prefix = 0, tot = 0;
+    int wave_prefix = 0, tot = 0;
     for (int w = 0; w < nw; ++w) {
-        long long s = lds_wave[w];
+        const int s = lds_wave[w];
         if (w < wave) wave_prefix += s;
         tot += s;
     }
@@ -231,74 +253,104 @@ __device__ __forceinline__ long long block_exclusive_scan(long long v, long long
     return wave_prefix + incl - v;
 }
 
-__global__ __launch_bounds__(256) void scan_tiles_kernel(Params p) {
-    __shared__ long long lds_wave[4];
+// grid = F blocks of 1024 threads; dynamic LDS = (2*T + 16 + 3*(kBuckets+1)) ints: counts[T], cursor[T], scratch, classes
+__global__ __launch_bounds__(1024) void bin_kernel(Params p) {
+    extern __shared__ int bin_lds[];
+    int *counts = bin_lds;
+    int *cursor = bin_lds + p.T;
+    int *scratch = bin_lds + 2 * p.T + 3 * (kBuckets + 1);
     const int f = blockIdx.x;
-    const int per = (p.T + 255) / 256;
-    const int t0 = threadIdx.x * per;
-    const int *cnt = p.buf.tile_count + (size_t)f * p.T;
-    int *off = p.buf.tile_off + (size_t)f * (p.T + 1);
-    long long local = 0;
-    for (int k = 0; k < per; ++k) {
-        int t = t0 + k;
-        if (t < p.T) local += cnt[t];
+    for (int t = threadIdx.x; t < p.T; t += blockDim.x) counts[t] = 0;
+    __syncthreads();
+
+    const float *vm = p.view + f * 16;
+    const float *pm = p.proj + f * 16;
+    const float tanx = p.tanfov[2 * f], tany = p.tanfov[2 * f + 1];
+    // phase 1: preprocess, count instances per tile (LDS atomics)
+    for (int i = threadIdx.x; i < p.N; i += blockDim.x) {
+        const uint4 rd = preprocess_one(p, f, i, vm, pm, tanx, tany);
+        const size_t gi = (size_t)f * p.N + i;
+        p.buf.rectd[gi] = rd;
+        if (p.out_radii) p.out_radii[gi] = (int)rd.w;
+        if (rd.w) {
+            const int rx0 = rd.x & 0xffff, ry0 = rd.x >> 16, rx1 = rd.y & 0xffff, ry1 = rd.y >> 16;
+            for (int ty = ry0; ty < ry1; ++ty)
+                for (int tx = rx0; tx < rx1; ++tx) atomicAdd(&counts[ty * p.gx + tx], 1);
+        }
     }
-    long long total;
-    long long prefix = block_exclusive_scan(local, lds_wave, &total);
-    int run = (int)prefix;
+    __syncthreads();
+
+    // phase 2: exclusive scan of the tile counters -> list offsets inside this frame's instance region
+    const int per = (p.T + (int)blockDim.x - 1) / (int)blockDim.x;
+    const int t0 = threadIdx.x * per;
+    int local = 0;
+    for (int k = 0; k < per; ++k)
+        if (t0 + k < p.T) local += counts[t0 + k];
+    int total;
+    int run = block_exclusive_scan(local, scratch, &total);
+    int *off = p.buf.tile_off + (size_t)f * (p.T + 1);
     for (int k = 0; k < per; ++k) {
-        int t = t0 + k;
+        const int t = t0 + k;
         if (t < p.T) {
-            int c = cnt[t];
+            const int c = counts[t];
+            cursor[t] = run;
             off[t] = run;
             run += c;
-            if (c > kSmallCap) {
-                int slot = atomicAdd(&p.buf.status->big_count, 1);
+            if (c > kSortCap) {
+                const int slot = atomicAdd(&p.buf.status->big_count, 1);
                 p.buf.big_list[slot] = f * p.T + t;
             }
         }
     }
-    if (threadIdx.x == 0) {
-        off[p.T] = (int)total;
-        p.buf.frame_total[f] = total;
-    }
-}
-
-__global__ __launch_bounds__(256) void scan_frames_kernel(Params p) {
-    __shared__ long long lds_wave[4];
-    long long carry = 0;
-    for (int base = 0; base < p.F; base += 256) {
-        int f = base + threadIdx.x;
-        long long v = f < p.F ? p.buf.frame_total[f] : 0;
-        long long total;
-        long long prefix = block_exclusive_scan(v, lds_wave, &total);
-        if (f < p.F) p.buf.frame_base[f] = carry + prefix;
-        carry += total;
-    }
-    if (threadIdx.x == 0) {
-        p.buf.status->total = carry;
-        p.buf.status->overflow = carry > p.capacity ? 1 : 0;
-    }
-}
-
-// -------------------------------------------------------------------------------------------------------- scatter
-__global__ __launch_bounds__(256) void scatter_kernel(Params p) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int f = blockIdx.y;
-    if (i >= p.N || p.buf.status->overflow) return;
-    const uint4 rd = p.buf.rectd[(size_t)f * p.N + i];
-    if (rd.w == 0u) return;
-    const int rx0 = rd.x & 0xffff, ry0 = rd.x >> 16, rx1 = rd.y & 0xffff, ry1 = rd.y >> 16;
-    const unsigned long long key = ((unsigned long long)rd.z << 32) | (unsigned)i;
-    int *cnt = p.buf.tile_count + (size_t)f * p.T;
-    const int *off = p.buf.tile_off + (size_t)f * (p.T + 1);
-    unsigned long long *keys = p.buf.keys + p.buf.frame_base[f];
-    for (int ty = ry0; ty < ry1; ++ty)
-        for (int tx = rx0; tx < rx1; ++tx) {
-            const int t = ty * p.gx + tx;
-            const int slot = atomicSub(cnt + t, 1) - 1;  // counters drain back to zero
-            keys[off[t] + slot] = key;
+    const bool fits = (long long)total <= p.cap_per_frame;
+    // work items of the blend kernel: non-empty tiles into this frame's queue, bucketed by list length; empty tiles
+    // into the fill list.  Two LDS-counted passes: count per class, reserve ranges with one global atomic each, emit.
+    int *cls = cursor + p.T;  // [kBuckets + 1] counts, then bases, then emit cursors (class kBuckets = empty)
+    constexpr int kCls = kBuckets + 1;
+    if (threadIdx.x < 3 * kCls) cls[threadIdx.x] = 0;
+    __syncthreads();
+    for (int k = 0; k < per; ++k)
+        if (t0 + k < p.T) {
+            const int c = fits ? counts[t0 + k] : 0;
+            atomicAdd(&cls[c == 0 ? kBuckets : bucket_of(c)], 1);
         }
+    __syncthreads();
+    const int qi = f % kQueues;
+    if (threadIdx.x < kBuckets) {
+        if (cls[threadIdx.x]) cls[kCls + threadIdx.x] = atomicAdd(&p.buf.status->qcount[qi][threadIdx.x], cls[threadIdx.x]);
+    } else if (threadIdx.x == kBuckets) {
+        cls[kCls + kBuckets] = atomicAdd(&p.buf.status->nempty, cls[kBuckets]);
+    }
+    __syncthreads();
+    for (int k = 0; k < per; ++k)
+        if (t0 + k < p.T) {
+            const int c = fits ? counts[t0 + k] : 0;
+            const int kind = c == 0 ? kBuckets : bucket_of(c);
+            const int pos = cls[kCls + kind] + atomicAdd(&cls[2 * kCls + kind], 1);
+            if (kind == kBuckets)
+                p.buf.empty_list[pos] = f * p.T + t0 + k;
+            else
+                p.buf.queue[((size_t)qi * kBuckets + kind) * p.qcap + pos] = f * p.T + t0 + k;
+        }
+    if (threadIdx.x == 0) {
+        off[p.T] = total;
+        atomicAdd(reinterpret_cast<unsigned long long *>(&p.buf.status->total), (unsigned long long)total);
+        atomicMax(reinterpret_cast<unsigned long long *>(&p.buf.status->max_frame), (unsigned long long)total);
+        if (!fits) atomicExch(&p.buf.status->overflow, 1);
+    }
+    __syncthreads();
+    if (!fits) return;
+
+    // phase 3: scatter (depth, index) keys into the tile lists (order inside a list is fixed later by the sort)
+    unsigned long long *keys = p.buf.keys + (size_t)f * p.cap_per_frame;
+    for (int i = threadIdx.x; i < p.N; i += blockDim.x) {
+        const uint4 rd = p.buf.rectd[(size_t)f * p.N + i];
+        if (rd.w == 0u) continue;
+        const int rx0 = rd.x & 0xffff, ry0 = rd.x >> 16, rx1 = rd.y & 0xffff, ry1 = rd.y >> 16;
+        const unsigned long long key = ((unsigned long long)rd.z << 32) | (unsigned)i;
+        for (int ty = ry0; ty < ry1; ++ty)
+            for (int tx = rx0; tx < rx1; ++tx) keys[atomicAdd(&cursor[ty * p.gx + tx], 1)] = key;
+    }
 }
 
 // ----------------------------------------------------------------------------------------------------------- sort
@@ -339,24 +391,6 @@ __device__ __forceinline__ void bitonic_sort(unsigned long long *a, int n, int t
     }
 }
 
-__global__ __launch_bounds__(256) void sort_small_kernel(Params p) {
-    __shared__ unsigned long long lds[4][kSmallCap];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const long long gt = (long long)blockIdx.x * 4 + wave;  // frame * T + tile
-    if (gt >= (long long)p.F * p.T || p.buf.status->overflow) return;
-    const int f = (int)(gt / p.T), t = (int)(gt % p.T);
-    const int *off = p.buf.tile_off + (size_t)f * (p.T + 1);
-    const int beg = off[t], n = off[t + 1] - beg;
-    if (n == 0 || n > kSmallCap) return;
-    const unsigned long long *keys = p.buf.keys + p.buf.frame_base[f] + beg;
-    unsigned *sorted = p.buf.sorted + p.buf.frame_base[f] + beg;
-    unsigned long long *a = lds[wave];
-    for (int k = lane; k < n; k += 64) a[k] = keys[k];
-    wave_sync();
-    bitonic_sort(a, n, lane, 64, [] { wave_sync(); });
-    for (int k = lane; k < n; k += 64) sorted[k] = (unsigned)(a[k] & 0xffffffffull);
-}
-
 __global__ __launch_bounds__(1024) void sort_big_kernel(Params p) {
     extern __shared__ unsigned long long big_lds[];
     if (p.buf.status->overflow) return;
@@ -366,8 +400,8 @@ __global__ __launch_bounds__(1024) void sort_big_kernel(Params p) {
         const int f = gt / p.T, t = gt % p.T;
         const int *off = p.buf.tile_off + (size_t)f * (p.T + 1);
         const int beg = off[t], n = off[t + 1] - beg;
-        unsigned long long *keys = p.buf.keys + p.buf.frame_base[f] + beg;
-        unsigned *sorted = p.buf.sorted + p.buf.frame_base[f] + beg;
+        unsigned long long *keys = p.buf.keys + (size_t)f * p.cap_per_frame + beg;
+        unsigned *sorted = p.buf.sorted + (size_t)f * p.cap_per_frame + beg;
         if (n <= kBigLdsCap) {
             for (int k = threadIdx.x; k < n; k += blockDim.x) big_lds[k] = keys[k];
             __syncthreads();
@@ -387,84 +421,172 @@ __global__ __launch_bounds__(1024) void sort_big_kernel(Params p) {
 }
 
 // --------------------------------------------------------------------------------------------------------- render
-// Blocks are dealt round-robin over the 8 XCDs; give each XCD a contiguous range of logical blocks (= frames).
-__device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nb) {
-    const unsigned xcd = b & 7u, q = nb >> 3, r = nb & 7u;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+struct WaveLds {
+    unsigned long long keys[kSortCap];  // keys, then (in place) the blend order as 32-bit Gaussian ids
+    float4 stage[3][64];
+};
+
+// One pixel, one Gaussian.  T > 0: live transmittance; T < 0: pixel finished, |T| is its final transmittance.
+template <bool kInvDepth>
+__device__ __forceinline__ void blend_px(float power2, float op, float cr, float cg, float cb, float invd, float &T,
+                                         float &Cr, float &Cg, float &Cb, float &Dp) {
+    const float alpha = fminf(0.99f, op * __builtin_amdgcn_exp2f(power2));
+    const bool valid = (power2 <= 0.0f) & (alpha >= (1.0f / 255.0f)) & (T > 0.0f);
+    const float test_T = T * (1.0f - alpha);
+    const bool fin = valid & (test_T < 0.0001f);
+    const bool acc = valid & !fin;
+    const float w = acc ? alpha * T : 0.0f;
+    Cr = fmaf(cr, w, Cr);
+    Cg = fmaf(cg, w, Cg);
+    Cb = fmaf(cb, w, Cb);
+    if (kInvDepth) Dp = fmaf(invd, w, Dp);
+    T = fin ? -T : (acc ? test_T : T);
 }
 
-template <bool kInvDepth>
-__global__ __launch_bounds__(256) void render_kernel(Params p, int blocks_per_frame) {
-    __shared__ float4 stage[4][3][64];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const unsigned b = xcd_remap(blockIdx.x, gridDim.x);
-    const int f = b / blocks_per_frame;
-    const int t = (b - f * blocks_per_frame) * 4 + wave;
-    if (t >= p.T) return;
-    const int tx = t % p.gx, ty = t / p.gx;
-    const int px = tx * kTile + (lane & 15);
-    const int py0 = ty * kTile + (lane >> 4);  // this lane's pixels: (px, py0 + 4k), k = 0..3
-    const float pxf = (float)px;
+#define AMAV_STAMP(slot)                                                                              \
+    do {                                                                                              \
+        if (p.stamps && lane == 0) p.stamps[(size_t)item * 6 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
 
-    float T[4] = {1.f, 1.f, 1.f, 1.f};
-    float Cr[4] = {0.f, 0.f, 0.f, 0.f}, Cg[4] = {0.f, 0.f, 0.f, 0.f}, Cb[4] = {0.f, 0.f, 0.f, 0.f};
-    float Dp[4] = {0.f, 0.f, 0.f, 0.f};
-    bool done[4];
-    float pyf[4];
+// Background for a tile without Gaussians: colour = bg, alpha = 0 (and inverse depth 0).
+template <bool kInvDepth>
+__device__ __forceinline__ void fill_tile(const Params &p, int item, int lane) {
+    const int f = item / p.T, t = item - f * p.T;
+    const int X0 = (t % p.gx) * kTile, Y0 = (t / p.gx) * kTile;
+    float r = p.bg[0], g = p.bg[1], bl = p.bg[2];
+    if (p.clamp_output) {
+        r = fminf(fmaxf(r, 0.f), 1.f);
+        g = fminf(fmaxf(g, 0.f), 1.f);
+        bl = fminf(fmaxf(bl, 0.f), 1.f);
+    }
+    // lane -> (column lane & 15, rows (lane >> 4) + 4k): every store instruction covers four full 256-byte tile rows
+    const int px = X0 + (lane & 15);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        pyf[k] = (float)(py0 + 4 * k);
-        done[k] = !(px < p.W && py0 + 4 * k < p.H);
+        const int py = Y0 + (lane >> 4) + 4 * k;
+        if (px < p.W && py < p.H) {
+            const size_t pid = ((size_t)f * p.H + py) * p.W + px;
+            reinterpret_cast<float4 *>(p.out_rgba)[pid] = make_float4(r, g, bl, 0.0f);
+            if (kInvDepth) p.out_inv_depth[pid] = 0.0f;
+        }
     }
+}
 
-    const bool overflow = p.buf.status->overflow != 0;
+// One non-empty tile, one wavefront.
+template <bool kInvDepth>
+__device__ __forceinline__ void render_tile(const Params &p, WaveLds &L, int item, int lane) {
+    const int f = item / p.T, t = item - f * p.T;
+    AMAV_STAMP(0);
+    const int tx = t % p.gx, ty = t / p.gx;
+    const int X0 = tx * kTile, Y0 = ty * kTile;
+    // this lane's four pixels: (X0 + 8*qx + lx, Y0 + 8*qy + ly), quadrant q = qx + 2*qy
+    const int lx = lane & 7, ly = lane >> 3;
+    float pxf0 = (float)(X0 + lx), pxf1 = (float)(X0 + 8 + lx);
+    float pyf0 = (float)(Y0 + ly), pyf1 = (float)(Y0 + 8 + ly);
+    asm volatile("" : "+v"(pxf0), "+v"(pxf1), "+v"(pyf0), "+v"(pyf1));  // keep them in registers (no re-convert)
+    const bool in0 = X0 + lx < p.W, in1 = X0 + 8 + lx < p.W, inr0 = Y0 + ly < p.H, inr1 = Y0 + 8 + ly < p.H;
+
+    float T0 = (in0 & inr0) ? 1.f : -1.f, T1 = (in1 & inr0) ? 1.f : -1.f;
+    float T2 = (in0 & inr1) ? 1.f : -1.f, T3 = (in1 & inr1) ? 1.f : -1.f;
+    float R0 = 0.f, G0 = 0.f, B0 = 0.f, D0 = 0.f, R1 = 0.f, G1 = 0.f, B1 = 0.f, D1 = 0.f;
+    float R2 = 0.f, G2 = 0.f, B2 = 0.f, D2 = 0.f, R3 = 0.f, G3 = 0.f, B3 = 0.f, D3 = 0.f;
+
     const int *off = p.buf.tile_off + (size_t)f * (p.T + 1);
     const int beg = off[t];
-    const int n = overflow ? 0 : off[t + 1] - beg;
-    if (n > 0) {
-        const unsigned *sorted = p.buf.sorted + p.buf.frame_base[f] + beg;
+    const int n = off[t + 1] - beg;
+    AMAV_STAMP(1);
+    if (p.stamps && lane == 0) p.stamps[(size_t)item * 6 + 5] = (unsigned long long)n;
+    {
+        const unsigned long long *keys = p.buf.keys + (size_t)f * p.cap_per_frame + beg;
+        const unsigned *order_g = p.buf.sorted + (size_t)f * p.cap_per_frame + beg;  // long lists only
+        unsigned *order_l = reinterpret_cast<unsigned *>(L.keys);
+        const bool local = n <= kSortCap;
+        if (local) {
+            // ---- rank sort in LDS: keys are unique, rank = number of smaller keys; up to 8 keys per lane, no
+            // cross-lane exchange.  The ids then overwrite the key slice (every lane has read all keys by then).
+            for (int k = lane; k < n; k += 64) L.keys[k] = keys[k];
+            wave_sync();
+            if (n <= kRankCap) {
+                unsigned long long my[4];
+                int rank[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int m = 0; m < 4; ++m) my[m] = (lane + 64 * m < n) ? L.keys[lane + 64 * m] : ~0ull;
+                for (int j = 0; j < n; ++j) {
+                    const unsigned long long kj = L.keys[j];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) rank[m] += (kj < my[m]) ? 1 : 0;
+                }
+                wave_sync();
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    if (lane + 64 * m < n) order_l[rank[m]] = (unsigned)my[m];
+            } else {
+                unsigned long long my[8];
+                int rank[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int m = 0; m < 8; ++m) my[m] = (lane + 64 * m < n) ? L.keys[lane + 64 * m] : ~0ull;
+                for (int j = 0; j < n; ++j) {
+                    const unsigned long long kj = L.keys[j];
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) rank[m] += (kj < my[m]) ? 1 : 0;
+                }
+                wave_sync();
+#pragma unroll
+                for (int m = 0; m < 8; ++m)
+                    if (lane + 64 * m < n) order_l[rank[m]] = (unsigned)my[m];
+            }
+            wave_sync();
+        }
+        AMAV_STAMP(2);
+
+        // ---- blend, 64 Gaussians per staging round
         const float4 *geom = p.buf.geom + (size_t)f * p.N * 3;
-        float4(*st)[64] = stage[wave];
         float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0, g2 = g0;
         if (lane < n) {
-            const float4 *g = geom + (size_t)sorted[lane] * 3;
+            const unsigned id = local ? order_l[lane] : order_g[lane];
+            const float4 *g = geom + (size_t)id * 3;
             g0 = g[0], g1 = g[1], g2 = g[2];
         }
-        for (int base = 0; base < n; base += 64) {
-            const int cnt = min(64, n - base);
-            st[0][lane] = g0;
-            st[1][lane] = g1;
-            st[2][lane] = g2;
+        const float X0f = (float)X0, Y0f = (float)Y0;
+        bool alive = true;
+        for (int base = 0; alive && base < n; base += 64) {
+            // quadrant mask of this lane's Gaussian: which 8x8 quadrants its alpha >= 1/255 box can reach
+            int qm = 0;
+            if (base + lane < n) {
+                const bool hx0 = (g0.x + g2.z >= X0f) & (g0.x - g2.z <= X0f + 7.f);
+                const bool hx1 = (g0.x + g2.z >= X0f + 8.f) & (g0.x - g2.z <= X0f + 15.f);
+                const bool hy0 = (g0.y + g2.w >= Y0f) & (g0.y - g2.w <= Y0f + 7.f);
+                const bool hy1 = (g0.y + g2.w >= Y0f + 8.f) & (g0.y - g2.w <= Y0f + 15.f);
+                qm = (int)(hx0 & hy0) | ((int)(hx1 & hy0) << 1) | ((int)(hx0 & hy1) << 2) | ((int)(hx1 & hy1) << 3);
+            }
+            const unsigned long long hit = __ballot(qm != 0);
+            const int cnt = __popcll(hit);
+            if (qm != 0) {
+                const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(hit >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hit, 0));
+                L.stage[0][pos] = g0;
+                L.stage[1][pos] = g1;
+                L.stage[2][pos] = make_float4(g2.x, g2.y, __int_as_float(qm), 0.f);
+            }
             wave_sync();
-            // prefetch the next chunk's records while this one is blended
+            // prefetch the next round's records while this one is blended
             if (base + 64 + lane < n) {
-                const float4 *g = geom + (size_t)sorted[base + 64 + lane] * 3;
+                const unsigned id = local ? order_l[base + 64 + lane] : order_g[base + 64 + lane];
+                const float4 *g = geom + (size_t)id * 3;
                 g0 = g[0], g1 = g[1], g2 = g[2];
             }
             for (int j = 0; j < cnt; ++j) {
-                const float4 a = st[0][j], bq = st[1][j], c = st[2][j];
-                const float dx = a.x - pxf;
-                const float adx2 = a.z * dx * dx;
-                const float bdx = a.w * dx;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float dy = a.y - pyf[k];
-                    const float power = -0.5f * (adx2 + bq.x * dy * dy) - bdx * dy;
-                    const float alpha = fminf(0.99f, bq.y * __expf(power));
-                    bool valid = !done[k] && power <= 0.0f && alpha >= (1.0f / 255.0f);
-                    const float test_T = T[k] * (1.0f - alpha);
-                    const bool fin = valid && test_T < 0.0001f;
-                    done[k] = done[k] || fin;
-                    valid = valid && !fin;
-                    const float w = valid ? alpha * T[k] : 0.0f;
-                    Cr[k] += bq.z * w;
-                    Cg[k] += bq.w * w;
-                    Cb[k] += c.x * w;
-                    if (kInvDepth) Dp[k] += c.y * w;
-                    T[k] = valid ? test_T : T[k];
-                }
-                if ((j & 15) == 15 && __all(done[0] && done[1] && done[2] && done[3])) {
-                    base = n;  // every pixel of the tile is saturated
+                const float4 a = L.stage[0][j], bq = L.stage[1][j], c = L.stage[2][j];
+                const int m = __builtin_amdgcn_readfirstlane(__float_as_int(c.z));
+                const float dx0 = a.x - pxf0, dx1 = a.x - pxf1, dy0 = a.y - pyf0, dy1 = a.y - pyf1;
+                const float ax0 = a.z * dx0 * dx0, ax1 = a.z * dx1 * dx1;
+                const float cy0 = bq.x * dy0 * dy0, cy1 = bq.x * dy1 * dy1;
+                const float bx0 = a.w * dx0, bx1 = a.w * dx1;
+                if (m & 1) blend_px<kInvDepth>(-0.5f * (ax0 + cy0) - bx0 * dy0, bq.y, bq.z, bq.w, c.x, c.y, T0, R0, G0, B0, D0);
+                if (m & 2) blend_px<kInvDepth>(-0.5f * (ax1 + cy0) - bx1 * dy0, bq.y, bq.z, bq.w, c.x, c.y, T1, R1, G1, B1, D1);
+                if (m & 4) blend_px<kInvDepth>(-0.5f * (ax0 + cy1) - bx0 * dy1, bq.y, bq.z, bq.w, c.x, c.y, T2, R2, G2, B2, D2);
+                if (m & 8) blend_px<kInvDepth>(-0.5f * (ax1 + cy1) - bx1 * dy1, bq.y, bq.z, bq.w, c.x, c.y, T3, R3, G3, B3, D3);
+                if ((j & 7) == 7 && __all((T0 < 0.f) & (T1 < 0.f) & (T2 < 0.f) & (T3 < 0.f))) {
+                    alive = false;  // every pixel of the tile is saturated
                     break;
                 }
             }
@@ -472,23 +594,62 @@ __global__ __launch_bounds__(256) void render_kernel(Params p, int blocks_per_fr
         }
     }
 
-    if (px < p.W) {
+    AMAV_STAMP(3);
+    // ---- write back: quadrant q of the wave = 8 rows x 128 B
+    const float Tq[4] = {fabsf(T0), fabsf(T1), fabsf(T2), fabsf(T3)};
+    const float Rq[4] = {R0, R1, R2, R3}, Gq[4] = {G0, G1, G2, G3}, Bq[4] = {B0, B1, B2, B3}, Dq[4] = {D0, D1, D2, D3};
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int py = py0 + 4 * k;
-            if (py < p.H) {
-                float r = Cr[k] + T[k] * p.bg[0], g = Cg[k] + T[k] * p.bg[1], bl = Cb[k] + T[k] * p.bg[2];
-                if (p.clamp_output) {
-                    r = fminf(fmaxf(r, 0.f), 1.f);
-                    g = fminf(fmaxf(g, 0.f), 1.f);
-                    bl = fminf(fmaxf(bl, 0.f), 1.f);
-                }
-                const size_t pid = ((size_t)f * p.H + py) * p.W + px;
-                reinterpret_cast<float4 *>(p.out_rgba)[pid] = make_float4(r, g, bl, 1.0f - T[k]);
-                if (kInvDepth) p.out_inv_depth[pid] = Dp[k];
+    for (int q = 0; q < 4; ++q) {
+        const int px = X0 + 8 * (q & 1) + lx, py = Y0 + 8 * (q >> 1) + ly;
+        if (px < p.W && py < p.H) {
+            float r = Rq[q] + Tq[q] * p.bg[0], g = Gq[q] + Tq[q] * p.bg[1], bl = Bq[q] + Tq[q] * p.bg[2];
+            if (p.clamp_output) {
+                r = fminf(fmaxf(r, 0.f), 1.f);
+                g = fminf(fmaxf(g, 0.f), 1.f);
+                bl = fminf(fmaxf(bl, 0.f), 1.f);
             }
+            const size_t pid = ((size_t)f * p.H + py) * p.W + px;
+            reinterpret_cast<float4 *>(p.out_rgba)[pid] = make_float4(r, g, bl, 1.0f - Tq[q]);
+            if (kInvDepth) p.out_inv_depth[pid] = Dq[q];
         }
     }
+    AMAV_STAMP(4);
+}
+
+__device__ __forceinline__ int xcc_id() {
+    int v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & (kQueues - 1);
+}
+
+// Blend kernel.  One block = up to four non-empty tiles (one per wave) + a share of the background tiles.  Tiles are
+// taken from bucketed lists, LONGEST LISTS FIRST: on this chip a dispatch recycles workgroup slots in dispatch order,
+// so a grid that mixes empty and long tiles strands most slots behind the long ones (measured 1.5 of 5 slots per CU
+// busy with one block per tile quad); with neighbours of similar length the hardware dispatcher balances the load.
+// Block b reads queue b % 8: blocks are dealt round-robin over the XCDs, so an XCD's L2 keeps seeing the frames of
+// its own queue (a placement assumption that only affects speed).
+template <bool kInvDepth>
+__global__ __launch_bounds__(256) void render_kernel(Params p) {
+    __shared__ WaveLds lds4[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const Status *st = p.buf.status;
+    const int gw = blockIdx.x * 4 + wave;
+    if (!st->overflow) {
+        const int q = blockIdx.x % kQueues;
+        const int i = (blockIdx.x / kQueues) * 4 + wave;  // position in queue q's concatenated buckets
+        int acc = 0, b = 0;
+        for (; b < kBuckets; ++b) {
+            const int c = st->qcount[q][b];
+            if (i < acc + c) break;
+            acc += c;
+        }
+        if (b < kBuckets)
+            render_tile<kInvDepth>(p, lds4[wave], p.buf.queue[((size_t)q * kBuckets + b) * p.qcap + (i - acc)], lane);
+    }
+    // background tiles (every tile when the instance regions overflowed: the caller must retry)
+    const int nempty = st->nempty;
+    const int nw = gridDim.x * 4, per = (nempty + nw - 1) / nw;
+    for (int k = gw * per; k < min(nempty, (gw + 1) * per); ++k) fill_tile<kInvDepth>(p, p.buf.empty_list[k], lane);
 }
 
 }  // namespace raster
@@ -501,7 +662,7 @@ extern "C" size_t amav_rasterize_workspace_bytes(int F, int N, int H, int W, int
     if (F <= 0 || N <= 0 || H <= 0 || W <= 0 || capacity < 0) return 0;
     const int gx = (W + kTile - 1) / kTile, gy = (H + kTile - 1) / kTile;
     size_t bytes = 0;
-    carve(nullptr, F, N, gx * gy, capacity, &bytes);
+    carve(nullptr, F, N, gx * gy, capacity / F * F, &bytes);
     return bytes;
 }
 
@@ -522,9 +683,14 @@ extern "C" int amav_rasterize_forward(const amav_raster_args *a, void *stream_) 
     AMAV_REQUIRE(gx < 65536 && gy < 65536, "amav_rasterize_forward: image too large");
     const int T = gx * gy;
     AMAV_REQUIRE((long long)F * T < (1ll << 31), "amav_rasterize_forward: F * tiles overflows int32");
+    const size_t bin_lds = ((size_t)2 * T + 16 + 3 * (kBuckets + 1)) * sizeof(int);
+    AMAV_REQUIRE(bin_lds <= 160 * 1024, "amav_rasterize_forward: %d tiles need %zu B of LDS in the binning block (max 160 KiB)",
+                 T, bin_lds);
+    const long long cap_per_frame = a->instance_capacity / F;
+    AMAV_REQUIRE(cap_per_frame < (1ll << 31), "amav_rasterize_forward: per-frame instance capacity overflows int32");
     size_t need = 0;
     Params p;
-    p.buf = carve(a->workspace, F, N, T, a->instance_capacity, &need);
+    p.buf = carve(a->workspace, F, N, T, cap_per_frame * F, &need);
     if (a->workspace_bytes < need)
         return fail(AMAV_ERR_WORKSPACE, "amav_rasterize_forward: workspace %zu < required %zu", a->workspace_bytes, need);
     p.F = F, p.N = N, p.H = a->height, p.W = a->width, p.gx = gx, p.gy = gy, p.T = T;
@@ -537,38 +703,39 @@ extern "C" int amav_rasterize_forward(const amav_raster_args *a, void *stream_) 
     p.scale_bias = a->scale_bias, p.scale_max = a->scale_max, p.opacity_bias = a->opacity_bias;
     p.antialiasing = a->antialiasing, p.clamp_output = a->clamp_output;
     p.out_rgba = a->out_rgba, p.out_inv_depth = a->out_inv_depth, p.out_radii = a->out_radii;
-    p.capacity = a->instance_capacity;
+    p.cap_per_frame = cap_per_frame;
+    p.qcap = (int)queue_capacity(F, T);
+    static const int debug_flags = getenv("AMAV_RASTER_DEBUG") ? atoi(getenv("AMAV_RASTER_DEBUG")) : 0;
+    p.debug_flags = debug_flags;
+    p.stamps = static_cast<unsigned long long *>(a->debug_stamps);
 
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    // tile counters + status start at zero (the counters also drain to zero in scatter; this covers first use
-    // and an overflowed previous call)
-    if (hipMemsetAsync(p.buf.status, 0, sizeof(Status), stream) != hipSuccess ||
-        hipMemsetAsync(p.buf.tile_count, 0, (size_t)F * T * sizeof(int), stream) != hipSuccess)
+    static const hipError_t attrs[2] = {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&sort_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            kBigLdsCap * sizeof(unsigned long long)),
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&bin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024)};
+    if (attrs[0] != hipSuccess || attrs[1] != hipSuccess)
+        return fail(AMAV_ERR_LAUNCH, "amav_rasterize_forward: cannot raise the dynamic LDS limit");
+    if (hipMemsetAsync(p.buf.status, 0, sizeof(Status), stream) != hipSuccess)
         return fail(AMAV_ERR_LAUNCH, "amav_rasterize_forward: hipMemsetAsync failed");
 
-    const dim3 ggrid((N + 255) / 256, F);
-    preprocess_kernel<<<ggrid, 256, 0, stream>>>(p);
-    scan_tiles_kernel<<<F, 256, 0, stream>>>(p);
-    scan_frames_kernel<<<1, 256, 0, stream>>>(p);
-    scatter_kernel<<<ggrid, 256, 0, stream>>>(p);
-    const long long ntile = (long long)F * T;
-    sort_small_kernel<<<(unsigned)((ntile + 3) / 4), 256, 0, stream>>>(p);
-    static const hipError_t big_attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&sort_big_kernel),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                           kBigLdsCap * sizeof(unsigned long long));
-    if (big_attr != hipSuccess)
-        return fail(AMAV_ERR_LAUNCH, "amav_rasterize_forward: cannot reserve %zu B of LDS for the big-tile sort",
-                    kBigLdsCap * sizeof(unsigned long long));
+    bin_kernel<<<F, 1024, bin_lds, stream>>>(p);
     sort_big_kernel<<<kBigBlocks, 1024, kBigLdsCap * sizeof(unsigned long long), stream>>>(p);
-    const int bpf = (T + 3) / 4;
+    // worst-case grid (every tile non-empty in one queue); must be a multiple of kQueues
+    const long long per_queue = ((long long)p.qcap + 3) / 4;
+    const unsigned blocks = (unsigned)(per_queue * kQueues);
+    if (a->profile_start_event) (void)hipEventRecord(static_cast<hipEvent_t>(a->profile_start_event), stream);
     if (a->out_inv_depth)
-        render_kernel<true><<<(unsigned)(bpf * F), 256, 0, stream>>>(p, bpf);
+        render_kernel<true><<<blocks, 256, 0, stream>>>(p);
     else
-        render_kernel<false><<<(unsigned)(bpf * F), 256, 0, stream>>>(p, bpf);
+        render_kernel<false><<<blocks, 256, 0, stream>>>(p);
+    if (a->profile_stop_event) (void)hipEventRecord(static_cast<hipEvent_t>(a->profile_stop_event), stream);
     return check_launch("amav_rasterize_forward");
 }
 
-extern "C" int amav_rasterize_status(const void *workspace, int64_t *total, int32_t *overflow, void *stream_) {
+extern "C" int amav_rasterize_status(const void *workspace, int64_t *total, int64_t *max_frame, int32_t *overflow,
+                                     void *stream_) {
     AMAV_REQUIRE(workspace != nullptr, "amav_rasterize_status: workspace is NULL");
     Status s;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -576,6 +743,7 @@ extern "C" int amav_rasterize_status(const void *workspace, int64_t *total, int3
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     if (e != hipSuccess) return fail(AMAV_ERR_LAUNCH, "amav_rasterize_status: %s", hipGetErrorString(e));
     if (total) *total = s.total;
+    if (max_frame) *max_frame = s.max_frame;
     if (overflow) *overflow = s.overflow;
     return AMAV_OK;
 }

@@ -46,6 +46,29 @@ def _attr(t: torch.Tensor, name: str, width: int) -> Attr:
     return Attr(t.data_ptr(), t.stride(0), t.stride(1), 0), t
 
 
+class Event:
+    """hipEvent through the C ABI (bench.py times the blend kernel with a pair of these)."""
+
+    def __init__(self):
+        h = ctypes.c_void_p()
+        check(_lib.lib().amav_event_create(ctypes.byref(h)), "amav_event_create")
+        self.handle = h
+
+    def record(self):
+        check(_lib.lib().amav_event_record(self.handle, _stream()), "amav_event_record")
+
+    def elapsed_ms(self, stop) -> float:
+        ms = ctypes.c_float(0)
+        check(_lib.lib().amav_event_elapsed_ms(self.handle, stop.handle, ctypes.byref(ms)), "amav_event_elapsed_ms")
+        return ms.value
+
+    def __del__(self):
+        try:
+            _lib.lib().amav_event_destroy(self.handle)
+        except Exception:
+            pass
+
+
 # --------------------------------------------------------------------------------------------------------- camera
 def camera_from_intrinsics(K, E, height, width, znear=0.01, zfar=100.0):
     """K [F,3,3], E [F,4,4] -> (viewmatrix [F,16], projmatrix [F,16], tanfov [F,2], campos [F,3]); no host sync.
@@ -82,10 +105,21 @@ class RasterWorkspace:
 
     def status(self):
         """(total_instances, overflowed) of the last forward.  Synchronises the current stream."""
-        total, over = ctypes.c_int64(0), ctypes.c_int32(0)
-        check(_lib.lib().amav_rasterize_status(self.buffer.data_ptr(), ctypes.byref(total), ctypes.byref(over),
-                                               _stream()), "amav_rasterize_status")
-        return total.value, bool(over.value)
+        total, _, over = self.status_full()
+        return total, over
+
+    def status_full(self):
+        """(total_instances, max_instances_of_a_frame, overflowed).  Synchronises the current stream."""
+        total, mx, over = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int32(0)
+        check(_lib.lib().amav_rasterize_status(self.buffer.data_ptr(), ctypes.byref(total), ctypes.byref(mx),
+                                               ctypes.byref(over), _stream()), "amav_rasterize_status")
+        return total.value, mx.value, bool(over.value)
+
+
+# When set to an (Event, Event) pair, the next rasterize() call records it around its blend kernel (bench.py).
+PROFILE_EVENTS = None
+# diagnostic: int64 CUDA tensor [F*tiles, 6] that receives the blend kernel's per-tile clock stamps (tools/)
+DEBUG_STAMPS = None
 
 
 def default_instance_capacity(num_frames, num_gaussians, per_gaussian=16):
@@ -94,7 +128,8 @@ def default_instance_capacity(num_frames, num_gaussians, per_gaussian=16):
 
 def rasterize(means3d, rotations, scales, opacities, colors, viewmatrix, projmatrix, tanfov, height, width,
               bg=(1.0, 1.0, 1.0), apply_activations=False, scale_modifier=1.0, antialiasing=False, clamp_output=False,
-              want_inv_depth=False, want_radii=False, workspace=None, check_overflow=True, out_rgba=None):
+              want_inv_depth=False, want_radii=False, workspace=None, check_overflow=True, out_rgba=None,
+              profile_events=None):
     """Batched tile rasterizer.  Gaussian attributes are [F,N,*] (frame stride 0 = shared across frames).
 
     Returns dict(rgba [F,H,W,4], inv_depth [F,H,W] | None, radii [F,N] | None, workspace).
@@ -144,18 +179,38 @@ def rasterize(means3d, rotations, scales, opacities, colors, viewmatrix, projmat
         args.out_radii = radii.data_ptr() if radii is not None else None
         args.workspace, args.workspace_bytes = ws.buffer.data_ptr(), ws.buffer.numel()
         args.instance_capacity = ws.capacity
+        if DEBUG_STAMPS is not None:
+            args.debug_stamps = DEBUG_STAMPS.data_ptr()
+        ev = profile_events if profile_events is not None else PROFILE_EVENTS
+        if ev is not None:
+            args.profile_start_event, args.profile_stop_event = ev[0].handle, ev[1].handle
         check(_lib.lib().amav_rasterize_forward(ctypes.byref(args), _stream()), "amav_rasterize_forward")
 
     launch(workspace)
     if check_overflow:
-        total, over = workspace.status()
-        if over:
-            workspace = RasterWorkspace(F, N, H, W, total, dev)
+        total, max_frame, over = workspace.status_full()
+        if over:  # every frame owns capacity / F instances: size the retry by the fullest frame
+            workspace = RasterWorkspace(F, N, H, W, F * max_frame, dev)
             launch(workspace)
-            total, over = workspace.status()
+            total, max_frame, over = workspace.status_full()
             if over:
-                raise AmavError(f"rasterizer overflowed twice (instances={total})")
+                raise AmavError(f"rasterizer overflowed twice (instances={total}, fullest frame {max_frame})")
     return dict(rgba=out_rgba, inv_depth=inv_depth, radii=radii, workspace=workspace)
+
+
+def frames_to_rgb8(rgba, out=None):
+    """fp32 RGBA [...,4] (contiguous) -> uint8 RGB [...,3], truncating like src/main2.py:351."""
+    rgba = _need(rgba, "rgba")
+    if not rgba.is_contiguous() or rgba.shape[-1] != 4:
+        raise AmavError("frames_to_rgb8: need a contiguous [...,4] tensor")
+    shape = tuple(rgba.shape[:-1]) + (3,)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.uint8, device=rgba.device)
+    elif tuple(out.shape) != shape or out.dtype != torch.uint8 or not out.is_contiguous():
+        raise AmavError(f"frames_to_rgb8: out must be contiguous uint8 {shape}")
+    check(_lib.lib().amav_frames_to_rgb8(rgba.numel() // 4, rgba.data_ptr(), out.data_ptr(), _stream()),
+          "amav_frames_to_rgb8")
+    return out
 
 
 # ------------------------------------------------------------------------------------------------------------ LBS

@@ -1,0 +1,271 @@
+"""Renderer and the splat entry points, on the HIP kernels (mirror of src/models/renderer.py).
+
+Kept verbatim from the reference: class / function names, argument order and meaning, the `gaussians` dict keys
+(`xyz, scale, rot, opacity, color, shs`, renderer.py:337-344), return shapes (`[B,T,H,W,3]` fp32 in [0,1], white
+background by default) and the parameter names of `gaussian_decoder.*` / `smpl_decoder.*` (checkpoint keys).
+
+Changed on purpose (MI355X-first):
+  * all frames of a call go through ONE batched launch per stage (the reference loops over frames in Python with
+    >= 6 host syncs per frame, renderer.py:475-477,501-510);
+  * triplane sampling + the five heads + construct_gaussians are one fused decode (csrc/triplane.hip) that never
+    materialises the [N, 3C] feature tensor; the Gaussians live in one packed [F,N,16] buffer and the dict entries
+    are views into it;
+  * the vertex subset is drawn once (seeded) instead of on every forward (renderer.py:287), and no stage prints or
+    synchronises (renderer.py:76-82);
+  * `upsample_triplane=True` and the PTv3 point refiner are SURVEY.md section 8(f) next-rows: requesting them raises.
+There is no CPU path: every tensor must be on the HIP device.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import AmavError
+from .body_model import SUBDIVIDE_VERTS, BodyModel, build_subdivision_table
+
+SUBDEVIDE_VERTS = SUBDIVIDE_VERTS  # the reference's spelling (renderer.py:14)
+SCALE_BIAS = ops.SCALE_BIAS
+OPACITY_BIAS = ops.OPACITY_BIAS
+
+
+def inverse_sigmoid(x):
+    """src/utils/math_utils.py:7-11."""
+    return torch.log(x / (1 - x)) if isinstance(x, torch.Tensor) else float(np.log(x / (1 - x)))
+
+
+class Renderer(nn.Module):
+    def __init__(self, cfg=None, smpl_decoder=None):
+        super().__init__()
+        self.cfg = cfg
+        if getattr(cfg, "upsample_triplane", False):
+            raise NotImplementedError("upsample_triplane=True (TriplaneUpsampler, renderer.py:377-417) is a SURVEY "
+                                      "8(f) next-row and is not built; set upsample_triplane=False")
+        if not getattr(cfg, "no_point_refiner", True):
+            raise NotImplementedError("the PTv3 point refiner (renderer.py:34-47,143-151) is a SURVEY 8(f) next-row; "
+                                      "set no_point_refiner=True (an untrained refiner outputs zero offsets anyway)")
+        self.smplx_model = self.init_smplx_model()
+        self.num_verts = SUBDEVIDE_VERTS[self.cfg.subdivide_steps]
+        self.init_smplx_subdivider(subdivide_steps=self.cfg.subdivide_steps)
+        self.smpl_decoder = smpl_decoder if cfg.predict_smplx_params else None
+
+        C = cfg.triplane_feature_dim
+        self.gaussian_decoder = nn.Module()
+        self.gaussian_decoder.xyz_layer = nn.Linear(C * 3 + 3, 3)
+        self.gaussian_decoder.rotation_layer = nn.Linear(C * 3 + 3, 4)
+        self.gaussian_decoder.scaling_layer = nn.Linear(C * 3 + 3, 3)
+        self.gaussian_decoder.opacity_layer = nn.Linear(C * 3 + 3, 1)
+        self.gaussian_decoder.shs_layer = nn.Linear(C * 3 + 3, 3)
+        # reference initialisation (renderer.py:57-71)
+        for layer in (self.gaussian_decoder.xyz_layer, self.gaussian_decoder.rotation_layer,
+                      self.gaussian_decoder.scaling_layer, self.gaussian_decoder.opacity_layer,
+                      self.gaussian_decoder.shs_layer):
+            nn.init.constant_(layer.weight, 0)
+            nn.init.constant_(layer.bias, 0)
+        nn.init.constant_(self.gaussian_decoder.rotation_layer.bias[0], 1.0)
+        nn.init.constant_(self.gaussian_decoder.scaling_layer.bias, -1.0)
+        nn.init.constant_(self.gaussian_decoder.opacity_layer.bias, inverse_sigmoid(0.1))
+        self._packed = None
+        self.to(cfg.device)
+
+    # ---- body model ------------------------------------------------------------------------------------------
+    def init_smplx_model(self):
+        """renderer.py:206-225.  Loads SMPLX_NEUTRAL.npz from cfg.smplx_model_path when present, else the seeded
+        SMPL-X-shaped synthetic body (the real model is licence-gated)."""
+        return BodyModel.create(getattr(self.cfg, "smplx_model_path", None), device=self.cfg.device, num_betas=10,
+                                num_expression_coeffs=self.cfg.num_expression_coeffs,
+                                flat_hand_mean=self.cfg.flat_hand_mean, seed=getattr(self.cfg, "body_seed", 42))
+
+    def init_smplx_subdivider(self, subdivide_steps=2):
+        """renderer.py:227-243: max(1, steps) edge-midpoint subdivisions, baked into one gather table together with
+        the vertex subset (drawn once from cfg.subset_seed instead of per forward, renderer.py:287)."""
+        levels = max(1, subdivide_steps)
+        table = build_subdivision_table(self.smplx_model.faces, self.smplx_model.num_verts, levels)
+        g = torch.Generator().manual_seed(int(getattr(self.cfg, "subset_seed", 42)))
+        idx = torch.randperm(table.shape[0], generator=g)[: self.num_verts]
+        self.subset_index = idx  # ids into the densified vertex list (kept for tests)
+        self.register_buffer("_gather_idx", torch.as_tensor(table)[idx].contiguous(), persistent=False)
+
+    def get_smpl_vertices(self, smpl_params):
+        """renderer.py:245-290: SMPL-X LBS for all B*T frames, then densify + subset.  -> [B*T, N, 3]"""
+        B, T = smpl_params["global_orient"].shape[:2]
+        r = lambda k: smpl_params[k].reshape(B * T, -1)
+        output = self.smplx_model(global_orient=r("global_orient"), body_pose=r("body_pose"), betas=r("betas"),
+                                  left_hand_pose=r("left_hand_pose"), right_hand_pose=r("right_hand_pose"),
+                                  jaw_pose=r("jaw_pose"), leye_pose=r("leye_pose"), reye_pose=r("reye_pose"),
+                                  expression=r("expression"))
+        vertices = output.vertices
+        if self.cfg.densify_smplx_verts:
+            vertices = ops.points_gather(vertices, self._gather_idx)
+        return vertices
+
+    # ---- triplane --------------------------------------------------------------------------------------------
+    def sample_from_triplane(self, triplane_features, points):
+        """renderer.py:292-317: planes [B,3,C,R,R] (or unbatched), points [B,N,3] -> [B,N,3C]."""
+        batched = points.ndim == 3
+        if not batched:
+            triplane_features, points = triplane_features[None], points[None]
+        out = ops.triplane_sample_features(triplane_features.float(), points.float(), self.cfg.radius)
+        return out if batched else out.squeeze(0)
+
+    def _head_weights(self):
+        gd = self.gaussian_decoder
+        layers = dict(xyz_layer=gd.xyz_layer, rotation_layer=gd.rotation_layer, scaling_layer=gd.scaling_layer,
+                      opacity_layer=gd.opacity_layer, shs_layer=gd.shs_layer)
+        version = tuple((l.weight._version, l.bias._version, l.weight.data_ptr()) for l in layers.values())
+        if self._packed is None or self._packed[0] != version:
+            heads = {k: (l.weight, l.bias) for k, l in layers.items()}
+            self._packed = (version, ops.pack_head_weights(heads, self.cfg.triplane_feature_dim,
+                                                           gd.xyz_layer.weight.device))
+        return self._packed[1]
+
+    def decode_gaussians(self, triplane_tokens, points, transl):
+        """Fused renderer.py:136-181: tokens [F,C,3R^2], points [F,N,3], transl [F,3] -> packed [F,N,16]."""
+        w_plane, w_point = self._head_weights()
+        proj = ops.triplane_project(triplane_tokens, w_plane, self.cfg.triplane_resolution)
+        return ops.triplane_sample_decode(proj, points, transl, self.cfg.radius, w_point)
+
+    @staticmethod
+    def unpack_gaussians(packed):
+        """Packed [F,N,16] records -> the reference's dict of (strided) views (renderer.py:337-344)."""
+        color = packed[..., ops.REC_COLOR:ops.REC_COLOR + 3]
+        return {"xyz": packed[..., ops.REC_XYZ:ops.REC_XYZ + 3], "scale": packed[..., ops.REC_SCALE:ops.REC_SCALE + 3],
+                "rot": packed[..., ops.REC_ROT:ops.REC_ROT + 4],
+                "opacity": packed[..., ops.REC_OPACITY:ops.REC_OPACITY + 1], "color": color, "shs": color}
+
+    def construct_gaussians(self, gaussian_params, points, smpl_params):
+        """renderer.py:319-346 for callers that computed the raw heads themselves (torch elementwise ops)."""
+        rotation = torch.nn.functional.normalize(gaussian_params["rotation"], dim=-1)
+        color = torch.sigmoid(gaussian_params["shs"])
+        return {"xyz": points + gaussian_params["xyz_offset"] + smpl_params["transl"].reshape(-1, 1, 3),
+                "scale": gaussian_params["scaling"], "rot": rotation, "opacity": gaussian_params["opacity"],
+                "color": color, "shs": color}
+
+    # ---- forward ---------------------------------------------------------------------------------------------
+    def forward(self, triplane_features, cam_params, smpl_tokens=None, smpl_params_gt=None):
+        """renderer.py:73-204.  triplane_features [B,T,C,3R^2] tokens, smpl_tokens [B,T,D,L]."""
+        if smpl_tokens is None:
+            raise AmavError("Renderer.forward needs smpl_tokens (the reference dereferences it too, renderer.py:84)")
+        B, T = smpl_tokens.shape[:2]
+        tokens = triplane_features.reshape(B * T, triplane_features.shape[2], triplane_features.shape[3]).float()
+
+        pred_smpl_params = None
+        if self.smpl_decoder is not None:
+            pred_smpl_params = self.smpl_decoder(smpl_tokens.reshape(B * T, *smpl_tokens.shape[2:]))
+            for key in list(pred_smpl_params.keys()):  # renderer.py:111-118
+                v = pred_smpl_params[key]
+                if key in ("body_pose", "left_hand_pose", "right_hand_pose"):
+                    pred_smpl_params[key] = v.reshape(B, T, *v.shape[1:])
+                else:
+                    pred_smpl_params[key] = v.reshape(B, T, -1)
+        smpl_params = smpl_params_gt if smpl_params_gt is not None else pred_smpl_params
+        if smpl_params is None:
+            raise AmavError("Renderer.forward: no SMPL-X parameters (predict_smplx_params is off and no smpl_params_gt)")
+
+        points = self.get_smpl_vertices(smpl_params)  # [B*T, N, 3]
+        packed = self.decode_gaussians(tokens, points, smpl_params["transl"].reshape(B * T, 3).float())
+        gaussians = self.unpack_gaussians(packed)
+        rendered_images = render_batch(gaussians, cam_params["intrinsic"], cam_params["extrinsic"], self.cfg)
+        if self.cfg.predict_smplx_params:
+            return rendered_images, gaussians, pred_smpl_params
+        return rendered_images, gaussians
+
+
+### Gaussian Splatting Renderer ###
+
+def _flat(t, width):
+    return t.reshape(-1, t.shape[-2], width).float()
+
+
+def render_multi_view(gaussians, K, E, args, bg_color=None, debug=False):
+    """renderer.py:431-445: one Gaussian set per batch item, T cameras.  The views share the Gaussians through a
+    zero frame stride instead of the reference's expand + reshape copy."""
+    B, T = E.shape[0], E.shape[1]
+    expanded = {k: v.unsqueeze(1).expand(-1, T, -1, -1) for k, v in gaussians.items()}
+    if B == 1:
+        expanded = {k: v[0] for k, v in expanded.items()}  # [T,N,D] with stride 0 over T: no copy
+    else:
+        expanded = {k: v.reshape(B * T, -1, v.shape[-1]) for k, v in expanded.items()}
+    rendered = render_batch(expanded, K, E, args, bg_color, debug)
+    return rendered.reshape(B, T, args.image_size[0], args.image_size[1], 3)
+
+
+def render_batch(gaussians, K, E, args, bg_color=None, debug=False, return_alpha=False, workspace=None,
+                 check_overflow=True, return_rgba=False):
+    """renderer.py:447-479: gaussians dict [(B*T),N,*], K [B,T,3,3], E [B,T,4,4] -> images [B,T,H,W,3] in [0,1].
+
+    One camera launch + one rasterizer launch sequence for all B*T frames.  The returned image is a view of the
+    kernel's RGBA output ([..., :3]); `return_alpha=True` also returns alpha [B,T,H,W] (= 1 - final transmittance);
+    `return_rgba=True` returns the contiguous [B,T,H,W,4] buffer itself.
+    """
+    if not getattr(args, "rgb", True):
+        raise NotImplementedError("args.rgb=False selects the reference's SH branch (renderer.py:540-545), which "
+                                  "cannot run with 3-channel colours (SURVEY.md Appendix C.4)")
+    B, T = E.shape[0], E.shape[1]
+    H, W = int(args.image_size[0]), int(args.image_size[1])
+    view, proj, tanfov, _ = ops.camera_from_intrinsics(K.reshape(-1, 3, 3).float(), E.reshape(-1, 4, 4).float(), H, W)
+    xyz, rot = _flat(gaussians["xyz"], 3), _flat(gaussians["rot"], 4)
+    scale, opacity, color = _flat(gaussians["scale"], 3), _flat(gaussians["opacity"], 1), _flat(gaussians["color"], 3)
+    if xyz.shape[0] != B * T:
+        raise AmavError(f"render_batch: {xyz.shape[0]} Gaussian sets for B*T = {B * T} cameras")
+    bg = [1.0, 1.0, 1.0] if bg_color is None else [float(c) for c in bg_color]
+    activate = True
+    if debug:  # renderer.py:535-537
+        scale = torch.full_like(scale, 0.01)
+        opacity = torch.full_like(opacity, 0.1)
+        color = color.clamp(0.0, 1.0)
+        activate = False
+    out = ops.rasterize(xyz, rot, scale, opacity, color, view, proj, tanfov, H, W, bg=bg, apply_activations=activate,
+                        clamp_output=True, workspace=workspace, check_overflow=check_overflow)
+    rgba = out["rgba"].view(B, T, H, W, 4)
+    if return_rgba:
+        return rgba
+    if return_alpha:
+        return rgba[..., :3], rgba[..., 3]
+    return rgba[..., :3]
+
+
+def render_one(xyzs, rots, scales, opacities, colors, K, E, args, bg_color=None, debug=False):
+    """renderer.py:481-569: one frame -> [3,H,W] clamped to [0,1]."""
+    g = {"xyz": xyzs[None], "rot": rots[None], "scale": scales[None], "opacity": opacities.reshape(1, -1, 1),
+         "color": colors[None]}
+    img = render_batch(g, K.reshape(1, 1, 3, 3), E.reshape(1, 1, 4, 4), args, bg_color, debug)
+    return img[0, 0].permute(2, 0, 1)
+
+
+# ---- op-level API of diff_gaussian_rasterization (renderer.py:516-566) --------------------------------------------
+class GaussianRasterizationSettings:
+    def __init__(self, image_height, image_width, tanfovx, tanfovy, bg, scale_modifier, viewmatrix, projmatrix,
+                 sh_degree, campos, prefiltered, debug, antialiasing=False):
+        self.image_height, self.image_width = int(image_height), int(image_width)
+        self.tanfovx, self.tanfovy = float(tanfovx), float(tanfovy)
+        self.bg, self.scale_modifier = bg, float(scale_modifier)
+        self.viewmatrix, self.projmatrix = viewmatrix, projmatrix
+        self.sh_degree, self.campos = sh_degree, campos
+        self.prefiltered, self.debug, self.antialiasing = prefiltered, debug, antialiasing
+
+
+class GaussianRasterizer(nn.Module):
+    """`GaussianRasterizer(raster_settings)(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+    cov3D_precomp)` -> (color [3,H,W], radii [N] int32, inv_depth [1,H,W]); inputs already activated."""
+
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def forward(self, means3D, means2D=None, shs=None, colors_precomp=None, opacities=None, scales=None,
+                rotations=None, cov3D_precomp=None):
+        s = self.raster_settings
+        if colors_precomp is None or shs is not None:
+            raise NotImplementedError("only colors_precomp is supported (the reference never passes shs, "
+                                      "renderer.py:561-562)")
+        if cov3D_precomp is not None or scales is None or rotations is None:
+            raise NotImplementedError("cov3D_precomp is not supported (the reference passes None, renderer.py:566)")
+        dev = means3D.device
+        out = ops.rasterize(means3D[None].float(), rotations[None].float(), scales[None].float(),
+                            opacities.reshape(1, -1, 1).float(), colors_precomp[None].float(),
+                            s.viewmatrix.reshape(1, 16).float(), s.projmatrix.reshape(1, 16).float(),
+                            torch.tensor([[s.tanfovx, s.tanfovy]], device=dev), s.image_height, s.image_width,
+                            bg=[float(b) for b in s.bg.detach().cpu().tolist()], scale_modifier=s.scale_modifier,
+                            antialiasing=s.antialiasing, want_inv_depth=True, want_radii=True)
+        color = out["rgba"][0, :, :, :3].permute(2, 0, 1)
+        return color, out["radii"][0], out["inv_depth"]

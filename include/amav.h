@@ -41,6 +41,12 @@ const char *amav_last_error(void);
 /* Number of visible HIP devices, or a negative error.  Does not create a context on a device. */
 int amav_device_count(void);
 
+/* Timing events for callers without a HIP binding of their own (thin hipEvent wrappers; elapsed synchronises). */
+int amav_event_create(void **event);
+int amav_event_destroy(void *event);
+int amav_event_record(void *event, void *stream);
+int amav_event_elapsed_ms(void *start, void *stop, float *ms);
+
 /* One per-Gaussian (or per-point) attribute: element (f, i) lives at ptr[f * frame_stride + i * elem_stride].
  * frame_stride = 0 broadcasts one set of Gaussians to every frame (render_multi_view, renderer.py:431-445). */
 typedef struct amav_attr {
@@ -93,16 +99,29 @@ typedef struct amav_raster_args {
     /* scratch */
     void *workspace;
     size_t workspace_bytes;
-    int64_t instance_capacity; /* max sum over frames of (tile, Gaussian) instances the workspace was sized for */
+    int64_t instance_capacity; /* instances the workspace was sized for; each frame owns capacity / F of them */
+    /* optional hipEvent_t pair (amav_event_create) recorded on `stream` right before / after the blend kernel, so a
+     * caller can time the dominant kernel live (bench.py roofline); NULL = off */
+    void *profile_start_event;
+    void *profile_stop_event;
+    /* diagnostic only: device buffer of num_frames * tiles * 6 uint64 that receives per-tile-wave clock stamps
+     * (start, ranges read, sorted, blended, stored) and the list length; NULL in production */
+    void *debug_stamps;
 } amav_raster_args;
 
 size_t amav_rasterize_workspace_bytes(int num_frames, int num_gaussians, int height, int width,
                                       int64_t instance_capacity);
 int amav_rasterize_forward(const amav_raster_args *args, void *stream);
-/* Synchronises `stream`, then reports the instance count of the last forward on this workspace and whether it
- * exceeded instance_capacity (in which case the outputs are invalid and the caller must retry with a workspace
- * sized for *total_instances).  The only rasterizer call that waits on the device. */
-int amav_rasterize_status(const void *workspace, int64_t *total_instances, int32_t *overflow, void *stream);
+/* Synchronises `stream`, then reports the last forward on this workspace: the total instance count, the largest
+ * per-frame count, and whether some frame exceeded its region (instance_capacity / num_frames instances each), in
+ * which case the outputs are invalid and the caller must retry with instance_capacity >= num_frames *
+ * *max_frame_instances.  The only rasterizer call that waits on the device. */
+int amav_rasterize_status(const void *workspace, int64_t *total_instances, int64_t *max_frame_instances,
+                          int32_t *overflow, void *stream);
+
+/* Rendered frames -> on-wire format of the multi-GPU exchange: fp32 RGBA [pixels,4] -> uint8 RGB [pixels,3] with the
+ * reference's own quantisation (src/main2.py:351: (frame * 255).astype(uint8), truncating). num_pixels % 4 == 0. */
+int amav_frames_to_rgb8(int64_t num_pixels, const float *rgba_dev, uint8_t *out_rgb8_dev, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * SMPL-X forward + linear blend skinning for F frames.

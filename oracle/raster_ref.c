@@ -87,13 +87,17 @@ static void merge_sort(inst_t *a, inst_t *tmp, int n) {
  * AFTER its own activations (renderer.py:532-547): scales are metric, opacities in (0,1), colours in [0,1],
  * rotations unit (w,x,y,z).  view/proj are the 16 floats of the transposed matrices (renderer.py:507-509).
  *
- * Outputs: color [3,H,W] planar, alpha [H,W] (= 1 - final T), inv_depth [H,W], radii [N].
+ * Outputs: color [3,H,W] planar, alpha [H,W] (= 1 - final T), inv_depth [H,W], radii [N], and (optional, may be
+ * NULL) unstable [H,W]: 1 where some blend decision of the pixel sat within a relative margin of 1e-4 of one of the
+ * algorithm's discontinuities (power > 0, alpha < 1/255, T' < 1e-4).  At such a pixel two correct fp32
+ * implementations may legitimately differ by one Gaussian's contribution (up to ~1/255); parity tests hold the
+ * 1e-3 bound on the other pixels and a one-flip bound on these (tests/test_raster_gpu.py).
  * Returns the number of (tile, Gaussian) instances, or -1 on allocation failure.
  */
 long oracle_rasterize(int N, int H, int W, const real *means3d, const real *rotations, const real *scales,
                       const real *opacities, const real *colors, const real *view, const real *proj, real tanfovx,
                       real tanfovy, const real *bg, real scale_modifier, int antialiasing, real *out_color,
-                      real *out_alpha, real *out_inv_depth, int32_t *out_radii) {
+                      real *out_alpha, real *out_inv_depth, int32_t *out_radii, uint8_t *out_unstable) {
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     const int ntiles = gx * gy;
     const real focal_x = (real)W / ((real)2.0 * tanfovx);
@@ -229,15 +233,21 @@ long oracle_rasterize(int N, int H, int W, const real *means3d, const real *rota
                 if (px >= W || py >= H) continue;
                 const real pxf = (real)px, pyf = (real)py;
                 real T = (real)1.0, C0 = 0, C1 = 0, C2 = 0, D = 0;
+                int unstable = 0;
+                const real margin = (real)1e-4;
                 for (int k = beg; k < end; ++k) {
                     const int id = inst[k].id;
                     real dx = xy[2 * id] - pxf, dy = xy[2 * id + 1] - pyf;
                     const real *co = conic_o + 4 * id;
                     real power = (real)-0.5 * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                    if (power > -margin * margin) unstable = 1;
                     if (power > (real)0.0) continue;
                     real alpha = R_FMIN((real)0.99, co[3] * R_EXP(power));
+                    if (alpha * (real)255.0 > (real)1.0 - margin && alpha * (real)255.0 < (real)1.0 + margin) unstable = 1;
                     if (alpha < (real)1.0 / (real)255.0) continue;
                     real test_T = T * ((real)1.0 - alpha);
+                    if (test_T > (real)0.0001 * ((real)1.0 - margin) && test_T < (real)0.0001 * ((real)1.0 + margin))
+                        unstable = 1;
                     if (test_T < (real)0.0001) break; /* pixel done; this Gaussian is not added */
                     C0 += colors[3 * id] * alpha * T;
                     C1 += colors[3 * id + 1] * alpha * T;
@@ -251,6 +261,7 @@ long oracle_rasterize(int N, int H, int W, const real *means3d, const real *rota
                 out_color[(size_t)2 * H * W + pid] = C2 + T * bg[2];
                 out_alpha[pid] = (real)1.0 - T;
                 out_inv_depth[pid] = D;
+                if (out_unstable) out_unstable[pid] = (uint8_t)unstable;
             }
     }
 

@@ -45,7 +45,8 @@ def rasterize_c(means3d, rotations, scales, opacities, colors, viewmatrix, projm
                 width, scale_modifier=1.0, antialiasing=False, dtype=np.float32):
     """One frame through raster_ref.c.  Inputs array-like (already activated, as renderer.py:557-566 passes them).
 
-    Returns dict(color [3,H,W], alpha [H,W], inv_depth [H,W], radii [N] int32, instances int).
+    Returns dict(color [3,H,W], alpha [H,W], inv_depth [H,W], radii [N] int32, instances int, unstable [H,W] u8:
+    pixels with a blend decision within 1e-4 (relative) of a discontinuity of the algorithm, see raster_ref.c).
     """
     dtype = np.dtype(dtype).type
     lib = _lib(dtype)
@@ -58,14 +59,15 @@ def rasterize_c(means3d, rotations, scales, opacities, colors, viewmatrix, projm
     alpha = np.zeros((height, width), dtype)
     invd = np.zeros((height, width), dtype)
     radii = np.zeros(N, np.int32)
+    unstable = np.zeros((height, width), np.uint8)
     ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)
     n = lib.oracle_rasterize(
         ctypes.c_int(N), ctypes.c_int(height), ctypes.c_int(width), ptr(m), ptr(r), ptr(s), ptr(o), ptr(c), ptr(v),
         ptr(p), c_real(tanfovx), c_real(tanfovy), ptr(b), c_real(scale_modifier), ctypes.c_int(int(antialiasing)),
-        ptr(color), ptr(alpha), ptr(invd), ptr(radii))
+        ptr(color), ptr(alpha), ptr(invd), ptr(radii), ptr(unstable))
     if n < 0:
         raise MemoryError("oracle_rasterize: allocation failed")
-    return dict(color=color, alpha=alpha, inv_depth=invd, radii=radii, instances=int(n))
+    return dict(color=color, alpha=alpha, inv_depth=invd, radii=radii, instances=int(n), unstable=unstable)
 
 
 def preprocess_torch(means3d, rotations, scales, opacities, view, proj, tanfovx, tanfovy, H, W, scale_modifier=1.0):
@@ -170,7 +172,7 @@ def render_one(xyzs, rots, scales, opacities, colors, K, E, image_size, bg_color
 
 
 def render_batch(gaussians, K, E, image_size, bg_color=None, debug=False, dtype=np.float32, full=False):
-    """renderer.py:447-479 -> [B,T,H,W,3] (and, with full=True, alpha [B,T,H,W])."""
+    """renderer.py:447-479 -> [B,T,H,W,3] (with full=True also alpha [B,T,H,W] and the unstable-pixel mask)."""
     B, T = E.shape[0], E.shape[1]
     tdt = torch.float64 if np.dtype(dtype) == np.float64 else torch.float32
     E_flat, K_flat = E.reshape(-1, 4, 4).to(tdt), K.reshape(-1, 3, 3).to(tdt)
@@ -179,15 +181,17 @@ def render_batch(gaussians, K, E, image_size, bg_color=None, debug=False, dtype=
     scales = gaussians["scale"].reshape(B * T, -1, 3).to(tdt)
     opac = gaussians["opacity"].reshape(B * T, -1, 1).to(tdt)
     cols = gaussians["color"].reshape(B * T, -1, 3).to(tdt)
-    imgs, alphas = [], []
+    imgs, alphas, unstable = [], [], []
     for i in range(B * T):
         img, out = render_one(xyzs[i], rots[i], scales[i], opac[i], cols[i], K_flat[i], E_flat[i], image_size,
                               bg_color, debug, dtype=dtype, full=True)
         imgs.append(img.permute(1, 2, 0))
         alphas.append(torch.from_numpy(out["alpha"]))
+        unstable.append(torch.from_numpy(out["unstable"]))
     images = torch.stack(imgs).reshape(B, T, image_size[0], image_size[1], 3)
     if full:
-        return images, torch.stack(alphas).reshape(B, T, image_size[0], image_size[1])
+        hw = (B, T, image_size[0], image_size[1])
+        return images, torch.stack(alphas).reshape(hw), torch.stack(unstable).reshape(hw).bool()
     return images
 
 

@@ -1,0 +1,127 @@
+"""Pins the SMPL-X / rotation / subdivision oracles by analytic properties and the golden fixtures."""
+import functools
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import random_pose
+from oracle import lbs, rotation, subdivide
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@functools.lru_cache(maxsize=1)
+def body():
+    from audio_motion_avatar_amd.body_model import BodyModel
+
+    return BodyModel.synthetic_model(seed=42, device="cpu")
+
+
+def test_rodrigues_quarter_turn_about_x():
+    R = lbs.batch_rodrigues(torch.tensor([[math.pi / 2, 0, 0]], dtype=torch.float64))[0]
+    assert torch.allclose(R, torch.tensor([[1, 0, 0], [0, 0, -1], [0, 1, 0]], dtype=torch.float64), atol=1e-7)
+
+
+def test_identity_pose_gives_shaped_template_exactly():
+    m = body().oracle_arrays(torch.float64)
+    coeffs = torch.zeros(2, 20, dtype=torch.float64)
+    coeffs[1, 0], coeffs[1, 12] = 1.5, -0.7
+    verts, joints, A = lbs.lbs(coeffs, torch.zeros(2, 165, dtype=torch.float64), m)
+    dirs = torch.cat([m["shapedirs"], m["expr_dirs"]], -1)
+    expect = m["v_template"] + torch.einsum("bl,mkl->bmk", coeffs, dirs)
+    assert (verts - expect).abs().max() < 1e-7   # angle = ||0 + 1e-8|| is not exactly zero
+    assert (A[:, :, :3, :3] - torch.eye(3, dtype=torch.float64)).abs().max() < 1e-7
+
+
+def test_global_orient_rotates_rigidly_about_the_pelvis():
+    m = body().oracle_arrays(torch.float64)
+    pose = torch.zeros(1, 165, dtype=torch.float64)
+    pose[0, :3] = torch.tensor([0.3, -0.8, 0.5])
+    zero = torch.zeros(1, 20, dtype=torch.float64)
+    verts, joints, _ = lbs.lbs(zero, pose, m)
+    rest, rest_j, _ = lbs.lbs(zero, torch.zeros(1, 165, dtype=torch.float64), m)
+    R = lbs.batch_rodrigues(pose[:, :3])[0]
+    expect = (rest[0] - rest_j[0, 0]) @ R.T + rest_j[0, 0]
+    # pose-corrective blend shapes depend only on joints 1..54, so they vanish here
+    assert (verts[0] - expect).abs().max() < 1e-6
+
+
+def test_lbs_golden_fixture_fp32():
+    g = np.load(os.path.join(GOLD, "lbs_synthetic42.npz"))
+    m = body().oracle_arrays(torch.float32)
+    verts, joints, A = lbs.lbs(torch.from_numpy(g["coeffs"]), torch.from_numpy(g["pose"]), m)
+    assert np.abs(verts.numpy() - g["vertices"]).max() < 1e-5
+    assert np.abs(joints.numpy() - g["joints"]).max() < 1e-5
+    assert np.abs(A[:, :, :3, :].numpy() - g["transforms"]).max() < 1e-5
+
+
+def test_smplx_forward_joint_order():
+    """full_pose = [global, body(21), jaw, leye, reye, lhand(15), rhand(15)]."""
+    m = body().oracle_arrays(torch.float64)
+    pose, coeffs = random_pose(3, 2)
+    pose, coeffs = pose.double(), coeffs.double()
+    v1, _ = lbs.smplx_forward(m, pose[:, :3], pose[:, 3:66], coeffs[:, :10], pose[:, 75:120], pose[:, 120:165],
+                              pose[:, 66:69], pose[:, 69:72], pose[:, 72:75], coeffs[:, 10:])
+    v2, _, _ = lbs.lbs(coeffs, pose, m)
+    assert torch.equal(v1, v2)
+
+
+def test_rot6d_round_trip_and_golden():
+    g = np.load(os.path.join(GOLD, "rot6d.npz"))
+    d6 = torch.from_numpy(g["d6"])
+    M = rotation.rotation_6d_to_matrix(d6)
+    assert (M @ M.transpose(1, 2) - torch.eye(3)).abs().max() < 1e-5
+    assert (torch.linalg.det(M) - 1).abs().max() < 1e-5
+    aa = rotation.matrix_to_axis_angle(M)
+    assert np.abs(aa.numpy() - g["axis_angle"]).max() < 1e-5
+    assert (lbs.batch_rodrigues(aa) - M).abs().max() < 1e-5   # what LBS sees downstream is M itself
+
+
+def test_product_rotation_conversion_matches_oracle():
+    from audio_motion_avatar_amd import smplx_decoder as sd
+
+    g = torch.Generator().manual_seed(0)
+    d6 = torch.randn(500, 6, generator=g, dtype=torch.float64)
+    M = rotation.rotation_6d_to_matrix(d6)
+    assert torch.allclose(sd.rotation_6d_to_matrix(d6), M, atol=1e-12)
+    assert torch.allclose(sd.matrix_to_axis_angle(M), rotation.matrix_to_axis_angle(M), atol=1e-10)
+    # near-identity rotations take the small-angle branch on both sides
+    tiny = torch.eye(3, dtype=torch.float64).expand(4, 3, 3).clone()
+    assert torch.allclose(sd.matrix_to_axis_angle(tiny), rotation.matrix_to_axis_angle(tiny))
+
+
+@pytest.mark.parametrize("levels", [1, 2])
+def test_baked_subdivision_table_is_bit_exact(levels):
+    """The product's [V',4] gather table evaluated as 1/2(1/2(a0+b0) + 1/2(a1+b1)) equals sequential subdivision."""
+    from audio_motion_avatar_amd.body_model import build_subdivision_table
+
+    b = body()
+    verts = torch.randn(2, b.num_verts, 3, generator=torch.Generator().manual_seed(1))
+    ref = verts
+    for edges in subdivide.subdivision_levels(b.faces, b.num_verts, levels):
+        ref = subdivide.subdivide_verts(ref, edges)
+    t = torch.as_tensor(build_subdivision_table(b.faces, b.num_verts, levels)).long()
+    p0 = (verts[:, t[:, 0]] + verts[:, t[:, 1]]) * 0.5
+    p1 = (verts[:, t[:, 2]] + verts[:, t[:, 3]]) * 0.5
+    assert torch.equal((p0 + p1) * 0.5, ref)
+    assert t.shape[0] == ref.shape[1]
+
+
+def test_synthetic_body_is_smplx_shaped():
+    from audio_motion_avatar_amd.body_model import SMPLX_PARENTS
+
+    b = body()
+    assert b.num_verts == 10475 and b.num_joints == 55
+    assert b._blend.shape == (20 + 54 * 9, 10475 * 3)
+    assert np.array_equal(b.parents, SMPLX_PARENTS) and b.parents[0] == -1 and (b.parents[1:] < np.arange(1, 55)).all()
+    w = b.lbs_weights
+    assert torch.allclose(w.sum(1), torch.ones(10475), atol=1e-6) and (w >= 0).all()
+    assert int((w != 0).sum(1).max()) <= 4 and b._skin_idx.shape[1] <= 4
+    assert b.faces.min() == 0 and b.faces.max() == 10474
+    # ELL skinning table reproduces the dense weights
+    dense = torch.zeros_like(w)
+    dense.scatter_add_(1, b._skin_idx.long(), b._skin_w)
+    assert torch.allclose(dense, w, atol=1e-7)

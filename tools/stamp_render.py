@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-phase clock stamps of the blend kernel on the bench workload (not part of the product path)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from audio_motion_avatar_amd import ops  # noqa: E402
+from audio_motion_avatar_amd.config import RendererConfig  # noqa: E402
+from audio_motion_avatar_amd.renderer import Renderer, render_batch  # noqa: E402
+from audio_motion_avatar_amd.synthetic import init_random_heads, make_render_inputs  # noqa: E402
+
+F = int(sys.argv[1]) if len(sys.argv) > 1 else 250
+cfg = RendererConfig(image_size=(512, 512), subdivide_steps=0, predict_smplx_params=False, device="cuda")
+r = init_random_heads(Renderer(cfg).eval())
+tokens, smpl, cam = make_render_inputs(F, cfg, seed=42)
+T = 32 * 32
+with torch.no_grad():
+    pts = r.get_smpl_vertices(smpl)
+    g = r.unpack_gaussians(r.decode_gaussians(tokens[0], pts, smpl["transl"].reshape(F, 3)))
+    for _ in range(2):
+        render_batch(g, cam["intrinsic"], cam["extrinsic"], cfg)
+    stamps = torch.zeros(F * T, 6, dtype=torch.int64, device="cuda")
+    ops.DEBUG_STAMPS = stamps
+    render_batch(g, cam["intrinsic"], cam["extrinsic"], cfg)
+    torch.cuda.synchronize()
+    ops.DEBUG_STAMPS = None
+s = stamps.cpu().numpy().astype(np.int64)
+n = s[:, 5]
+ne = s[:, 0] != 0
+US = 0.01  # s_memrealtime ticks at 100 MHz
+t0 = s[ne, 0].min()
+span = (s[ne, 4].max() - t0) * US
+print(f"tiles {len(n)}, nonempty {ne.sum()}, mean n (nonempty) {n[ne].mean():.1f}, max n {n.max()}, kernel span {span:.1f} us")
+sn = s[ne]
+ph = [(sn[:, i + 1] - sn[:, i]) * US for i in range(4)]
+for nm, d in zip(["read ranges", "load+sort", "blend", "store"], ph):
+    print(f"  {nm:12s} wave-time total {d.sum() / 1e3:8.2f} ms   mean {d.mean():7.2f} us   p99 {np.percentile(d, 99):7.2f} us")
+for lo, hi in ((1, 32), (32, 64), (64, 128), (128, 256), (256, 512), (512, 10**9)):
+    m = (sn[:, 5] >= lo) & (sn[:, 5] < hi)
+    if m.any():
+        print(f"  n in [{lo},{hi}): {m.sum():6d} tiles  sort {ph[1][m].mean():7.2f} us  blend {ph[2][m].mean():7.2f} us  "
+              f"blend/gaussian {ph[2][m].sum() / sn[m, 5].sum() * 1e3:6.1f} ns")
+ev = np.concatenate([np.stack([sn[:, 0], np.ones(len(sn))], 1), np.stack([sn[:, 4], -np.ones(len(sn))], 1)])
+ev = ev[np.argsort(ev[:, 0], kind="stable")]
+conc = np.cumsum(ev[:, 1])
+ts = (ev[:, 0] - t0) * US
+for q in np.linspace(0, ts.max(), 21)[1:]:
+    i = np.searchsorted(ts, q) - 1
+    hv = ((sn[:, 0] - t0) * US <= q) & ((sn[:, 4] - t0) * US >= q)
+    print(f"  t={q:7.1f} us  waves in flight {int(conc[i]):5d}  (nonempty {int(hv.sum())})")
