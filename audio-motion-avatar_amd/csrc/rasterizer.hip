@@ -11,7 +11,7 @@
 //                  the memory side on MI355X (the eight XCD L2s are not coherent; measured 0.43 ms per 8.4 M adds);
 //                  LDS atomics do not.  Frames own fixed instance regions, so there is no cross-frame scan and no
 //                  host round trip (upstream syncs to read the instance count).
-//   sort_big       persistent blocks sort the rare tile lists longer than 512 in LDS (<= 16 K keys) or in place.
+//   sort_big       persistent blocks sort the tile lists longer than 512 in LDS (<= 2 K keys) or in place.
 //   render_kernel  ONE WAVEFRONT PER TILE: loads its keys, sorts them in its LDS slice (rank sort <= 256 keys,
 //                  normalised bitonic <= 512; keys are unique, so the order equals upstream's stable radix sort by
 //                  (tile, depth)), then blends 4 pixels per lane -- one in each 8x8 quadrant of the tile.  Gaussians
@@ -31,10 +31,9 @@ namespace amav {
 namespace raster {
 
 constexpr int kTile = AMAV_TILE;
-constexpr int kRankCap = 256;      // keys a wave rank-sorts (4 per lane)
 constexpr int kSortCap = 512;      // keys a wave sorts in its LDS slice (4 KiB); longer lists go to sort_big
-constexpr int kBigLdsCap = 16384;  // keys a 1024-thread block sorts in LDS (128 KiB)
-constexpr int kBigBlocks = 256;
+constexpr int kBigLdsCap = 2048;   // keys a sort_big block sorts in LDS (16 KiB); longer lists are sorted in place
+constexpr int kBigBlocks = 1280;
 constexpr float kLog2e = 1.4426950408889634f;
 
 constexpr int kQueues = 8;    // one work queue per XCD (frame f feeds queue f % 8, so an XCD's L2 sees whole frames)
@@ -391,8 +390,8 @@ __device__ __forceinline__ void bitonic_sort(unsigned long long *a, int n, int t
     }
 }
 
-__global__ __launch_bounds__(1024) void sort_big_kernel(Params p) {
-    extern __shared__ unsigned long long big_lds[];
+__global__ __launch_bounds__(256) void sort_big_kernel(Params p) {
+    __shared__ unsigned long long big_lds[kBigLdsCap];
     if (p.buf.status->overflow) return;
     const int count = p.buf.status->big_count;
     for (int w = blockIdx.x; w < count; w += gridDim.x) {
@@ -425,6 +424,36 @@ struct WaveLds {
     unsigned long long keys[kSortCap];  // keys, then (in place) the blend order as 32-bit Gaussian ids
     float4 stage[3][64];
 };
+
+// Rank sort of n <= 64 * KPL unique keys held in LDS: rank = number of smaller keys, no cross-lane exchange.  The
+// 32-bit ids then overwrite the key slice in blend order (every lane has read all keys by then).
+template <int KPL>
+__device__ __forceinline__ void rank_sort(unsigned long long *keys, unsigned *order, int n, int lane) {
+    unsigned long long my[KPL];
+    int rank[KPL];
+#pragma unroll
+    for (int m = 0; m < KPL; ++m) {
+        my[m] = (lane + 64 * m < n) ? keys[lane + 64 * m] : ~0ull;
+        rank[m] = 0;
+    }
+    int j = 0;
+    for (; j + 4 <= n; j += 4) {  // four broadcast reads in flight per round
+        const unsigned long long k0 = keys[j], k1 = keys[j + 1], k2 = keys[j + 2], k3 = keys[j + 3];
+#pragma unroll
+        for (int m = 0; m < KPL; ++m)
+            rank[m] += (int)(k0 < my[m]) + (int)(k1 < my[m]) + (int)(k2 < my[m]) + (int)(k3 < my[m]);
+    }
+    for (; j < n; ++j) {
+        const unsigned long long kj = keys[j];
+#pragma unroll
+        for (int m = 0; m < KPL; ++m) rank[m] += (int)(kj < my[m]);
+    }
+    wave_sync();
+#pragma unroll
+    for (int m = 0; m < KPL; ++m)
+        if (lane + 64 * m < n) order[rank[m]] = (unsigned)my[m];
+    wave_sync();
+}
 
 // One pixel, one Gaussian.  T > 0: live transmittance; T < 0: pixel finished, |T| is its final transmittance.
 template <bool kInvDepth>
@@ -502,40 +531,16 @@ __device__ __forceinline__ void render_tile(const Params &p, WaveLds &L, int ite
         unsigned *order_l = reinterpret_cast<unsigned *>(L.keys);
         const bool local = n <= kSortCap;
         if (local) {
-            // ---- rank sort in LDS: keys are unique, rank = number of smaller keys; up to 8 keys per lane, no
-            // cross-lane exchange.  The ids then overwrite the key slice (every lane has read all keys by then).
             for (int k = lane; k < n; k += 64) L.keys[k] = keys[k];
             wave_sync();
-            if (n <= kRankCap) {
-                unsigned long long my[4];
-                int rank[4] = {0, 0, 0, 0};
-#pragma unroll
-                for (int m = 0; m < 4; ++m) my[m] = (lane + 64 * m < n) ? L.keys[lane + 64 * m] : ~0ull;
-                for (int j = 0; j < n; ++j) {
-                    const unsigned long long kj = L.keys[j];
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) rank[m] += (kj < my[m]) ? 1 : 0;
-                }
-                wave_sync();
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-                    if (lane + 64 * m < n) order_l[rank[m]] = (unsigned)my[m];
-            } else {
-                unsigned long long my[8];
-                int rank[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-                for (int m = 0; m < 8; ++m) my[m] = (lane + 64 * m < n) ? L.keys[lane + 64 * m] : ~0ull;
-                for (int j = 0; j < n; ++j) {
-                    const unsigned long long kj = L.keys[j];
-#pragma unroll
-                    for (int m = 0; m < 8; ++m) rank[m] += (kj < my[m]) ? 1 : 0;
-                }
-                wave_sync();
-#pragma unroll
-                for (int m = 0; m < 8; ++m)
-                    if (lane + 64 * m < n) order_l[rank[m]] = (unsigned)my[m];
-            }
-            wave_sync();
+            if (n <= 64)
+                rank_sort<1>(L.keys, order_l, n, lane);
+            else if (n <= 128)
+                rank_sort<2>(L.keys, order_l, n, lane);
+            else if (n <= 256)
+                rank_sort<4>(L.keys, order_l, n, lane);
+            else
+                rank_sort<8>(L.keys, order_l, n, lane);
         }
         AMAV_STAMP(2);
 
@@ -548,9 +553,9 @@ __device__ __forceinline__ void render_tile(const Params &p, WaveLds &L, int ite
             g0 = g[0], g1 = g[1], g2 = g[2];
         }
         const float X0f = (float)X0, Y0f = (float)Y0;
-        bool alive = true;
-        for (int base = 0; alive && base < n; base += 64) {
-            // quadrant mask of this lane's Gaussian: which 8x8 quadrants its alpha >= 1/255 box can reach
+        int qalive = 15;  // quadrants that still have an unfinished pixel (wave-uniform)
+        for (int base = 0; qalive && base < n; base += 64) {
+            // quadrant mask of this lane's Gaussian: which live 8x8 quadrants its alpha >= 1/255 box can reach
             int qm = 0;
             if (base + lane < n) {
                 const bool hx0 = (g0.x + g2.z >= X0f) & (g0.x - g2.z <= X0f + 7.f);
@@ -558,6 +563,7 @@ __device__ __forceinline__ void render_tile(const Params &p, WaveLds &L, int ite
                 const bool hy0 = (g0.y + g2.w >= Y0f) & (g0.y - g2.w <= Y0f + 7.f);
                 const bool hy1 = (g0.y + g2.w >= Y0f + 8.f) & (g0.y - g2.w <= Y0f + 15.f);
                 qm = (int)(hx0 & hy0) | ((int)(hx1 & hy0) << 1) | ((int)(hx0 & hy1) << 2) | ((int)(hx1 & hy1) << 3);
+                qm &= qalive;
             }
             const unsigned long long hit = __ballot(qm != 0);
             const int cnt = __popcll(hit);
@@ -574,21 +580,28 @@ __device__ __forceinline__ void render_tile(const Params &p, WaveLds &L, int ite
                 const float4 *g = geom + (size_t)id * 3;
                 g0 = g[0], g1 = g[1], g2 = g[2];
             }
+            // software pipeline: record j+1 is read from LDS while record j is blended
+            float4 a = L.stage[0][0], bq = L.stage[1][0], c = L.stage[2][0];
             for (int j = 0; j < cnt; ++j) {
-                const float4 a = L.stage[0][j], bq = L.stage[1][j], c = L.stage[2][j];
-                const int m = __builtin_amdgcn_readfirstlane(__float_as_int(c.z));
-                const float dx0 = a.x - pxf0, dx1 = a.x - pxf1, dy0 = a.y - pyf0, dy1 = a.y - pyf1;
-                const float ax0 = a.z * dx0 * dx0, ax1 = a.z * dx1 * dx1;
-                const float cy0 = bq.x * dy0 * dy0, cy1 = bq.x * dy1 * dy1;
-                const float bx0 = a.w * dx0, bx1 = a.w * dx1;
-                if (m & 1) blend_px<kInvDepth>(-0.5f * (ax0 + cy0) - bx0 * dy0, bq.y, bq.z, bq.w, c.x, c.y, T0, R0, G0, B0, D0);
-                if (m & 2) blend_px<kInvDepth>(-0.5f * (ax1 + cy0) - bx1 * dy0, bq.y, bq.z, bq.w, c.x, c.y, T1, R1, G1, B1, D1);
-                if (m & 4) blend_px<kInvDepth>(-0.5f * (ax0 + cy1) - bx0 * dy1, bq.y, bq.z, bq.w, c.x, c.y, T2, R2, G2, B2, D2);
-                if (m & 8) blend_px<kInvDepth>(-0.5f * (ax1 + cy1) - bx1 * dy1, bq.y, bq.z, bq.w, c.x, c.y, T3, R3, G3, B3, D3);
-                if ((j & 7) == 7 && __all((T0 < 0.f) & (T1 < 0.f) & (T2 < 0.f) & (T3 < 0.f))) {
-                    alive = false;  // every pixel of the tile is saturated
-                    break;
+                const int jn = min(j + 1, 63);
+                const float4 an = L.stage[0][jn], bn = L.stage[1][jn], cn = L.stage[2][jn];
+                const int m = __builtin_amdgcn_readfirstlane(__float_as_int(c.z)) & qalive;
+                if (m) {
+                    const float dx0 = a.x - pxf0, dx1 = a.x - pxf1, dy0 = a.y - pyf0, dy1 = a.y - pyf1;
+                    const float ax0 = a.z * dx0 * dx0, ax1 = a.z * dx1 * dx1;
+                    const float cy0 = bq.x * dy0 * dy0, cy1 = bq.x * dy1 * dy1;
+                    const float bx0 = a.w * dx0, bx1 = a.w * dx1;
+                    if (m & 1) blend_px<kInvDepth>(-0.5f * (ax0 + cy0) - bx0 * dy0, bq.y, bq.z, bq.w, c.x, c.y, T0, R0, G0, B0, D0);
+                    if (m & 2) blend_px<kInvDepth>(-0.5f * (ax1 + cy0) - bx1 * dy0, bq.y, bq.z, bq.w, c.x, c.y, T1, R1, G1, B1, D1);
+                    if (m & 4) blend_px<kInvDepth>(-0.5f * (ax0 + cy1) - bx0 * dy1, bq.y, bq.z, bq.w, c.x, c.y, T2, R2, G2, B2, D2);
+                    if (m & 8) blend_px<kInvDepth>(-0.5f * (ax1 + cy1) - bx1 * dy1, bq.y, bq.z, bq.w, c.x, c.y, T3, R3, G3, B3, D3);
                 }
+                if ((j & 7) == 7) {  // a quadrant whose 64 pixels are all finished takes no further Gaussians
+                    qalive = (__any(T0 > 0.f) ? 1 : 0) | (__any(T1 > 0.f) ? 2 : 0) | (__any(T2 > 0.f) ? 4 : 0) |
+                             (__any(T3 > 0.f) ? 8 : 0);
+                    if (!qalive) break;
+                }
+                a = an, bq = bn, c = cn;
             }
             wave_sync();
         }
@@ -710,18 +723,14 @@ extern "C" int amav_rasterize_forward(const amav_raster_args *a, void *stream_) 
     p.stamps = static_cast<unsigned long long *>(a->debug_stamps);
 
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    static const hipError_t attrs[2] = {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&sort_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            kBigLdsCap * sizeof(unsigned long long)),
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&bin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024)};
-    if (attrs[0] != hipSuccess || attrs[1] != hipSuccess)
-        return fail(AMAV_ERR_LAUNCH, "amav_rasterize_forward: cannot raise the dynamic LDS limit");
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&bin_kernel),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (attr != hipSuccess) return fail(AMAV_ERR_LAUNCH, "amav_rasterize_forward: cannot raise the dynamic LDS limit");
     if (hipMemsetAsync(p.buf.status, 0, sizeof(Status), stream) != hipSuccess)
         return fail(AMAV_ERR_LAUNCH, "amav_rasterize_forward: hipMemsetAsync failed");
 
     bin_kernel<<<F, 1024, bin_lds, stream>>>(p);
-    sort_big_kernel<<<kBigBlocks, 1024, kBigLdsCap * sizeof(unsigned long long), stream>>>(p);
+    sort_big_kernel<<<kBigBlocks, 256, 0, stream>>>(p);
     // worst-case grid (every tile non-empty in one queue); must be a multiple of kQueues
     const long long per_queue = ((long long)p.qcap + 3) / 4;
     const unsigned blocks = (unsigned)(per_queue * kQueues);

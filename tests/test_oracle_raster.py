@@ -36,8 +36,10 @@ def test_single_centred_gaussian_closed_form():
     np.testing.assert_allclose(o["inv_depth"][32, 32], a / z, atol=1e-12)
     # sigma_px = 0.02 * 64 / 2 = 0.64 px (+0.3 low-pass): one pixel away alpha = o * exp(-0.5 / (0.64^2 + 0.3))
     var = 0.64 ** 2 + 0.3
-    np.testing.assert_allclose(o["alpha"][32, 33], a * math.exp(-0.5 / var), rtol=1e-9)
-    assert o["radii"][0] == math.ceil(3 * math.sqrt(var))
+    # (rtol 1e-4: the mean sits 0.5 px off the optical axis, so the EWA Jacobian adds a (x/z)^2 ~ 6e-5 term)
+    np.testing.assert_allclose(o["alpha"][32, 33], a * math.exp(-0.5 / var), rtol=1e-4)
+    # radius: lambda_max = mid + sqrt(max(0.1, mid^2 - det)); isotropic => the 0.1 floor applies
+    assert o["radii"][0] == math.ceil(3 * math.sqrt(var + math.sqrt(0.1)))
 
 
 def test_opacity_is_capped_at_099():
