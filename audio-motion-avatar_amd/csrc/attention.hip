@@ -1,7 +1,183 @@
-// placeholder until the MFMA kernel lands (fails loudly; never computes on the CPU)
+// Self-attention of the audio transformer on the gfx950 matrix cores, exact fp32.
+//
+// Replaces diffusers' Attention -> F.scaled_dot_product_attention as reached from BasicTransformerBlock.attn1
+// (src/models/transformers.py:329-336; 8 heads x 64, S = 2 * (3 * 32^2 + 80) = 6304 tokens, no mask).  This is the
+// only dense contraction of the hot path (the audio cross-attention has ONE key, so it is a
+// broadcast, not a contraction); it runs on v_mfma_f32_32x32x2_f32, whose products and sums are exact IEEE fp32
+// (the reference runs fp32 SDPA; bf16 would threaten the 1e-3 image bound through the autoregressive recurrence).
+//
+// Flash-style, one pass over the keys with an online softmax, never materialising the S x S scores:
+//   * a workgroup = 4 waves = 128 queries of one (batch, head); each wave owns 32 queries for the whole key sweep;
+//   * the product is computed TRANSPOSED, S^T = K Q^T (keys on the MFMA rows, queries on the columns): a lane then
+//     holds one query's scores in its accumulator registers, so the row max / row sum are register reductions plus
+//     one exchange between the two lane halves, and P^T is already in the B-operand layout of the next product
+//     O^T = V^T P^T -- the probabilities never leave the registers;
+//   * K is staged in LDS transposed ([d][key], padded) and V row-major, which makes every operand fetch a
+//     conflict-free 32-lane row read; the next K/V tile is prefetched into registers under the current tile's MFMAs.
 #include "amav_common.h"
+
+namespace amav {
+namespace attn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kD = 64;        // head dim
+constexpr int kBM = 128;      // queries per workgroup (4 waves x 32)
+constexpr int kBN = 64;       // keys per tile
+constexpr int kLdk = kBN + 1; // padded row of the transposed K tile
+
+__global__ __launch_bounds__(256) void selfattn_kernel(const float *__restrict__ q, const float *__restrict__ k,
+                                                       const float *__restrict__ v, float *__restrict__ out, int S,
+                                                       long long row_stride, long long out_row_stride,
+                                                       float scale_log2e) {
+    __shared__ float Kt[kD * kLdk];   // [d][key]
+    __shared__ float Vs[kBN * kD];    // [key][d]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int c = lane & 31, hh = lane >> 5;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * kBM + wave * 32;
+    const size_t base = (size_t)b * S;
+
+    // Q fragment (B operand of S^T = K Q^T): Q[q0 + c][2 s + hh], pre-scaled by softmax_scale * log2(e)
+    float Qr[32];
+    {
+        const float *qrow = q + (base + min(q0 + c, S - 1)) * row_stride + head * kD;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            const float2 t = *reinterpret_cast<const float2 *>(qrow + 2 * s);
+            Qr[s] = (hh ? t.y : t.x) * scale_log2e;
+        }
+    }
+
+    f32x16 O0, O1;  // O^T: rows d (0..31 / 32..63), column = this lane's query
+#pragma unroll
+    for (int t = 0; t < 16; ++t) O0[t] = 0.f, O1[t] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;
+
+    // staging map: thread -> key (tid / 16 + 16 i), 4 consecutive d at (tid % 16) * 4
+    const int skey = tid >> 4, sd = (tid & 15) * 4;
+    float4 k0, k1, k2, k3, v0, v1, v2, v3;  // named registers: an indexed array here is demoted to scratch
+#define AMAV_LOAD_ONE(kt_, i_, kr_, vr_)                                             \
+    {                                                                                \
+        const int key_ = min((kt_) * kBN + skey + 16 * (i_), S - 1);                 \
+        const size_t off_ = (base + key_) * row_stride + head * kD + sd;             \
+        kr_ = *reinterpret_cast<const float4 *>(k + off_);                           \
+        vr_ = *reinterpret_cast<const float4 *>(v + off_);                           \
+    }
+#define AMAV_LOAD_TILE(kt_) \
+    AMAV_LOAD_ONE(kt_, 0, k0, v0) AMAV_LOAD_ONE(kt_, 1, k1, v1) AMAV_LOAD_ONE(kt_, 2, k2, v2) AMAV_LOAD_ONE(kt_, 3, k3, v3)
+#define AMAV_STAGE_ONE(i_, kr_, vr_)                                  \
+    {                                                                 \
+        const int key_ = skey + 16 * (i_);                            \
+        Kt[(sd + 0) * kLdk + key_] = kr_.x;                           \
+        Kt[(sd + 1) * kLdk + key_] = kr_.y;                           \
+        Kt[(sd + 2) * kLdk + key_] = kr_.z;                           \
+        Kt[(sd + 3) * kLdk + key_] = kr_.w;                           \
+        *reinterpret_cast<float4 *>(&Vs[key_ * kD + sd]) = vr_;      \
+    }
+    const int ntiles = (S + kBN - 1) / kBN;
+    AMAV_LOAD_TILE(0)
+    for (int kt = 0; kt < ntiles; ++kt) {
+        // ---- stage tile kt (K transposed, V as is)
+        AMAV_STAGE_ONE(0, k0, v0) AMAV_STAGE_ONE(1, k1, v1) AMAV_STAGE_ONE(2, k2, v2) AMAV_STAGE_ONE(3, k3, v3)
+        __syncthreads();
+        if (kt + 1 < ntiles) {  // in flight under this tile's MFMAs
+            AMAV_LOAD_TILE(kt + 1)
+        }
+
+        // ---- S^T = K Q^T for the two 32-key halves of the tile
+        f32x16 S0, S1;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) S0[t] = 0.f, S1[t] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            const float a0 = Kt[(2 * s + hh) * kLdk + c];
+            const float a1 = Kt[(2 * s + hh) * kLdk + 32 + c];
+            S0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, Qr[s], S0, 0, 0, 0);
+            S1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, Qr[s], S1, 0, 0, 0);
+        }
+        // accumulator register t of key half kb holds key  kt*64 + kb*32 + (t&3) + 8*(t>>2) + 4*hh
+        if ((kt + 1) * kBN > S) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int kk = kt * kBN + (t & 3) + 8 * (t >> 2) + 4 * hh;
+                if (kk >= S) S0[t] = -1e30f;
+                if (kk + 32 >= S) S1[t] = -1e30f;
+            }
+        }
+        // ---- online softmax over this lane's query
+        float mx = S0[0];
+#pragma unroll
+        for (int t = 1; t < 16; ++t) mx = fmaxf(mx, S0[t]);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) mx = fmaxf(mx, S1[t]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float corr = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            S0[t] = __builtin_amdgcn_exp2f(S0[t] - m_new);
+            S1[t] = __builtin_amdgcn_exp2f(S1[t] - m_new);
+            psum += S0[t] + S1[t];
+        }
+        l_run = l_run * corr + psum;  // per-half partial sum; the halves are added once at the end
+#pragma unroll
+        for (int t = 0; t < 16; ++t) O0[t] *= corr, O1[t] *= corr;
+
+        // ---- O^T += V^T P^T: accumulator register t is the B operand of k-step {key r, key r + 4}
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int r = (t & 3) + 8 * (t >> 2) + 4 * hh;
+            O0 = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[r * kD + c], S0[t], O0, 0, 0, 0);
+            O1 = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[r * kD + 32 + c], S0[t], O1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int r = 32 + (t & 3) + 8 * (t >> 2) + 4 * hh;
+            O0 = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[r * kD + c], S1[t], O0, 0, 0, 0);
+            O1 = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[r * kD + 32 + c], S1[t], O1, 0, 0, 0);
+        }
+        __syncthreads();  // every wave is done with this tile before it is overwritten
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (q0 + c < S) {
+        float *orow = out + (base + q0 + c) * out_row_stride + head * kD;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {  // registers 4g..4g+3 are 4 consecutive d: 8g + 4hh + (0..3)
+            const int d = 8 * g + 4 * hh;
+            *reinterpret_cast<float4 *>(orow + d) =
+                make_float4(O0[4 * g] * inv, O0[4 * g + 1] * inv, O0[4 * g + 2] * inv, O0[4 * g + 3] * inv);
+            *reinterpret_cast<float4 *>(orow + 32 + d) =
+                make_float4(O1[4 * g] * inv, O1[4 * g + 1] * inv, O1[4 * g + 2] * inv, O1[4 * g + 3] * inv);
+        }
+    }
+}
+
+}  // namespace attn
+}  // namespace amav
+
 using namespace amav;
-extern "C" int amav_selfattn_forward(int, int, int, int, const float *, const float *, const float *, int64_t, float *,
-                                     int64_t, float, void *) {
-    return fail(AMAV_ERR_LAUNCH, "amav_selfattn_forward: kernel not built in this revision");
+
+extern "C" int amav_selfattn_forward(int B, int S, int H, int D, const float *q, const float *k, const float *v,
+                                     int64_t row_stride, float *out, int64_t out_row_stride, float scale,
+                                     void *stream) {
+    AMAV_REQUIRE(B > 0 && S > 0 && H > 0, "amav_selfattn_forward: bad sizes B=%d S=%d H=%d", B, S, H);
+    AMAV_REQUIRE(D == attn::kD, "amav_selfattn_forward: head_dim %d (only %d is built)", D, attn::kD);
+    AMAV_REQUIRE(q && k && v && out, "amav_selfattn_forward: NULL pointer");
+    AMAV_REQUIRE(row_stride >= (int64_t)H * D && out_row_stride >= (int64_t)H * D && row_stride % 4 == 0 &&
+                     out_row_stride % 4 == 0,
+                 "amav_selfattn_forward: row strides must be multiples of 4 floats and >= H*D");
+    AMAV_REQUIRE(((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v) |
+                   reinterpret_cast<uintptr_t>(out)) & 15) == 0,
+                 "amav_selfattn_forward: q/k/v/out must be 16-byte aligned");
+    AMAV_REQUIRE(H <= 65535 && B <= 65535, "amav_selfattn_forward: grid too large");
+    const dim3 grid((S + attn::kBM - 1) / attn::kBM, H, B);
+    attn::selfattn_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(q, k, v, out, S, row_stride,
+                                                                             out_row_stride,
+                                                                             scale * 1.4426950408889634f);
+    return check_launch("amav_selfattn_forward");
 }

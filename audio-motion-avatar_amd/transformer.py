@@ -1,0 +1,136 @@
+"""Transformer1D_nn and its blocks (mirror of the live part of src/models/transformers.py).
+
+Same module tree and parameter names as the reference, so `audio_triplane.transformer.*` checkpoint keys load:
+    norm, proj_in, transformer_blocks.N.{norm1, attn1.{to_q,to_k,to_v,to_out.0}, norm2, attn2.{...}, norm3,
+    ff.net.0.proj, ff.net.2}, proj_out          (transformers.py:980-1011,225-275,438-444,497)
+Only the configuration AudioTriplaneNet uses is built (norm_type="layer_norm", GEGLU feed-forward, no dropout,
+attention_bias=False, cross-attention to the audio token; triplane_audio_net.py:132-141).
+
+What runs where:
+  * self-attention (attn1, S = 6304 tokens, 8 x 64): the hand-written fp32 MFMA flash kernel (csrc/attention.hip),
+    fed by ONE fused q/k/v projection GEMM whose output it reads in place through a row stride;
+  * cross-attention (attn2): the context is a single audio token (triplane_audio_net.py:211), so softmax over one
+    key is exactly 1 and the layer is to_out(to_v(audio)) broadcast over the tokens -- computed exactly that way
+    (two [1,768]x[768,512] products instead of 6304 x 512 x 2 of wasted Q/K work);
+  * LayerNorm / GroupNorm / Linear: library kernels through torch (rocBLAS / hipBLASLt fp32 GEMMs).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+
+class Attention(nn.Module):
+    """diffusers `Attention` as configured by the reference: q/k/v without bias, out with
+    bias, scale 1/sqrt(dim_head), no mask."""
+
+    def __init__(self, query_dim, cross_attention_dim=None, heads=8, dim_head=64, dropout=0.0, bias=False):
+        super().__init__()
+        inner = heads * dim_head
+        self.heads, self.dim_head, self.inner_dim = heads, dim_head, inner
+        self.is_cross = cross_attention_dim is not None
+        ctx = cross_attention_dim if self.is_cross else query_dim
+        self.to_q = nn.Linear(query_dim, inner, bias=bias)
+        self.to_k = nn.Linear(ctx, inner, bias=bias)
+        self.to_v = nn.Linear(ctx, inner, bias=bias)
+        self.to_out = nn.ModuleList([nn.Linear(inner, query_dim), nn.Dropout(dropout)])
+        self._qkv = None
+
+    def _qkv_weight(self):
+        ws = (self.to_q.weight, self.to_k.weight, self.to_v.weight)
+        version = tuple((w._version, w.data_ptr()) for w in ws)
+        if self._qkv is None or self._qkv[0] != version:
+            self._qkv = (version, torch.cat([w.detach() for w in ws], dim=0).contiguous())
+        return self._qkv[1]
+
+    def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None):
+        if attention_mask is not None:
+            raise NotImplementedError("attention masks are not used on this path (transformers.py:1026-1031)")
+        if encoder_hidden_states is None:
+            B, S, _ = hidden_states.shape
+            qkv = F.linear(hidden_states, self._qkv_weight())          # [B,S,3*inner], one GEMM
+            i = self.inner_dim
+            out = ops.selfattn(qkv[..., :i], qkv[..., i:2 * i], qkv[..., 2 * i:], self.heads)
+            return self.to_out[0](out)
+        if encoder_hidden_states.shape[1] != 1:
+            raise NotImplementedError("cross-attention over more than one context token is not on the reference's "
+                                      "path (triplane_audio_net.py:211 passes audio_features[:, t:t+1])")
+        # one key: softmax == 1, so the output is to_out(to_v(context)) for every query
+        ctx = self.to_out[0](self.to_v(encoder_hidden_states))        # [B,1,query_dim]
+        return ctx.expand(-1, hidden_states.shape[1], -1)
+
+
+class GEGLU(nn.Module):
+    """transformers.py:484-508: proj to 2*inner, first half = value, second half = gate, exact-erf GELU."""
+
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.proj = nn.Linear(dim_in, dim_out * 2)
+
+    def forward(self, hidden_states):
+        hidden_states, gate = self.proj(hidden_states).chunk(2, dim=-1)
+        return hidden_states * F.gelu(gate)
+
+
+class FeedForward(nn.Module):
+    """transformers.py:402-452 with activation_fn='geglu': net = [GEGLU, Dropout, Linear]."""
+
+    def __init__(self, dim, mult=4, dropout=0.0):
+        super().__init__()
+        inner = int(dim * mult)
+        self.net = nn.ModuleList([GEGLU(dim, inner), nn.Dropout(dropout), nn.Linear(inner, dim)])
+
+    def forward(self, hidden_states):
+        for module in self.net:
+            hidden_states = module(hidden_states)
+        return hidden_states
+
+
+class BasicTransformerBlock(nn.Module):
+    """transformers.py:140-399, layer_norm variant: LN -> self-attn -> LN -> cross-attn -> LN -> GEGLU FF."""
+
+    def __init__(self, dim, num_attention_heads, attention_head_dim, dropout=0.0, cross_attention_dim=None):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn1 = Attention(dim, None, num_attention_heads, attention_head_dim, dropout)
+        self.norm2 = nn.LayerNorm(dim)
+        self.attn2 = Attention(dim, cross_attention_dim, num_attention_heads, attention_head_dim, dropout)
+        self.norm3 = nn.LayerNorm(dim)
+        self.ff = FeedForward(dim, dropout=dropout)
+
+    def forward(self, hidden_states, encoder_hidden_states=None):
+        hidden_states = self.attn1(self.norm1(hidden_states)) + hidden_states
+        hidden_states = self.attn2(self.norm2(hidden_states), encoder_hidden_states) + hidden_states
+        return self.ff(self.norm3(hidden_states)) + hidden_states
+
+
+class Transformer1D_nn(nn.Module):
+    """transformers.py:912-1074: [B,C,S] tokens (+ [B,1,ctx] audio) -> [B,C,S]."""
+
+    def __init__(self, num_attention_heads=16, attention_head_dim=88, in_channels=None, out_channels=None,
+                 num_layers=1, dropout=0.0, norm_num_groups=32, cross_attention_dim=None, norm_type="layer_norm",
+                 enable_memory_efficient_attention=False, gradient_checkpointing=False, **unused):
+        super().__init__()
+        if in_channels is None:
+            raise ValueError("in_channels must be defined")
+        if norm_type != "layer_norm":
+            raise NotImplementedError("only norm_type='layer_norm' is on the reference's path")
+        inner = num_attention_heads * attention_head_dim
+        self.in_channels = in_channels
+        self.norm = nn.GroupNorm(norm_num_groups, in_channels, eps=1e-6, affine=True)
+        self.proj_in = nn.Linear(in_channels, inner)
+        self.transformer_blocks = nn.ModuleList([
+            BasicTransformerBlock(inner, num_attention_heads, attention_head_dim, dropout, cross_attention_dim)
+            for _ in range(num_layers)])
+        self.proj_out = nn.Linear(inner, in_channels)
+
+    def forward(self, hidden_states, encoder_hidden_states=None):
+        batch, channels, seq_len = hidden_states.shape
+        residual = hidden_states
+        h = self.norm(hidden_states).permute(0, 2, 1)
+        h = self.proj_in(h)
+        for block in self.transformer_blocks:
+            h = block(h, encoder_hidden_states)
+        h = self.proj_out(h).permute(0, 2, 1)
+        return h + residual

@@ -1,0 +1,84 @@
+"""GPU parity of the audio-driven token generator (Transformer1D_nn on the MFMA attention kernel + the temporal
+reducers + the autoregressive loop) against the functional CPU oracle, on a reduced-width configuration."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def small_cfg():
+    from audio_motion_avatar_amd.config import AudioNetConfig, ModelConfig, RendererConfig
+
+    a = AudioNetConfig(triplane_feature_dim=32, triplane_resolution=8, smpl_token_len=10, smpl_token_dim=32,
+                       transformer_layers=2, transformer_head_dim=64, transformer_num_heads=2, audio_feature_dim=48,
+                       triplane_output_frames=3)
+    r = RendererConfig(triplane_feature_dim=32, triplane_resolution=8, smpl_token_len=10, smpl_token_dim=32,
+                       image_size=(64, 64), subdivide_steps=0)
+    return ModelConfig(triplane_audio_net=a, renderer=r)
+
+
+def randomize(module, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            if "conv_time" in name:
+                p.copy_(torch.rand(p.shape, generator=g))
+            elif p.dim() > 1:
+                p.copy_(torch.randn(p.shape, generator=g) * (0.5 / p.shape[-1] ** 0.5))
+            else:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.1 + (1.0 if "norm" in name and "weight" in name else 0.0))
+
+
+def test_token_generation_matches_oracle():
+    from audio_motion_avatar_amd.triplane_audio_net import AudioTriplaneNet
+    from oracle import transformer as o_tr
+
+    cfg = small_cfg()
+    net = AudioTriplaneNet(cfg, renderer=None).eval()
+    randomize(net, 0)
+    params = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    net = net.cuda()
+    g = torch.Generator().manual_seed(1)
+    B = 2
+    audio = torch.randn(B, 4, 48, generator=g)
+    tri = torch.randn(B, 2, 32, 3 * 64, generator=g)
+    smpl = torch.randn(B, 2, 32, 10, generator=g)
+    with torch.no_grad():
+        got_tri, got_smpl = net.generate_tokens(audio.cuda(), tri.cuda(), smpl.cuda())
+        ref_tri, ref_smpl = o_tr.audio_triplane_tokens(params, audio, tri, smpl, resolution=8, smpl_len=10, t_output=3,
+                                                       num_layers=2, heads=2)
+    assert got_tri.shape == (B, 3, 32, 192) and got_smpl.shape == (B, 3, 32, 10)
+    scale = ref_tri.abs().max().item()
+    assert (got_tri.cpu() - ref_tri).abs().max() <= 2e-4 * max(1.0, scale)
+    assert (got_smpl.cpu() - ref_smpl).abs().max() <= 2e-4 * max(1.0, scale)
+
+
+def test_forward_returns_the_reference_five_tuple():
+    """AudioTriplaneNet(cfg, renderer).forward(audio, tokens, ref_image_features, cam, smpl_tokens)
+    (triplane_audio_net.py:157,271)."""
+    from audio_motion_avatar_amd.renderer import Renderer
+    from audio_motion_avatar_amd.smplx_decoder import SMPLXDecoder
+    from audio_motion_avatar_amd.synthetic import init_random_heads, make_render_inputs
+    from audio_motion_avatar_amd.triplane_audio_net import AudioTriplaneNet
+
+    cfg = small_cfg()
+    renderer = init_random_heads(Renderer(cfg.renderer, smpl_decoder=SMPLXDecoder(cfg.renderer)).eval())
+    net = AudioTriplaneNet(cfg, renderer=renderer).eval()
+    randomize(net.transformer, 3)
+    net = net.cuda()
+    B, T = 1, 3
+    _, _, cam = make_render_inputs(T, cfg.renderer, seed=5, batch=B)
+    g = torch.Generator().manual_seed(2)
+    audio = torch.randn(B, 8, 48, generator=g).cuda()
+    tri = torch.randn(B, 2, 32, 192, generator=g).cuda()
+    smpl = (torch.randn(B, 2, 32, 10, generator=g) * 0.2).cuda()
+    with torch.no_grad():
+        images, gaussians, smpl_params, out_tri, out_smpl = net(audio, tri, None, cam, smpl)
+    assert images.shape == (B, T, 64, 64, 3) and out_tri.shape == (B, T, 32, 192) and out_smpl.shape == (B, T, 32, 10)
+    assert set(gaussians) == {"xyz", "scale", "rot", "opacity", "color", "shs"}
+    assert smpl_params["global_orient"].shape == (B, T, 3)
+    assert torch.isfinite(images).all() and 0.0 <= float(images.min()) and float(images.max()) <= 1.0
+    # chaining as the demo loop does (main2.py:202-203): the last two outputs seed the next window
+    with torch.no_grad():
+        nxt = net(audio[:, 3:], out_tri[:, -2:], None, cam, out_smpl[:, -2:])
+    assert nxt[0].shape == images.shape
