@@ -39,21 +39,112 @@ def parse():
     ap.add_argument("--image", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the workload timed on the CPU oracle")
-    ap.add_argument("--no-graph", action="store_true", help="do not capture the step into a hipGraph")
+    ap.add_argument("--workload", choices=["render", "full"], default="render",
+                    help="render = BASELINE configs[1] (static decode + LBS + rasterize, the metric's config); "
+                         "full = configs[2]: synthetic audio tokens -> AudioTriplaneNet (autoregressive) -> SMPL-X "
+                         "decoder -> LBS -> decode -> rasterize")
     return ap.parse_args()
 
 
-def build_renderer(args, device):
+def build_renderer(args, device, with_decoder=False):
     from audio_motion_avatar_amd.config import RendererConfig
     from audio_motion_avatar_amd.renderer import Renderer
+    from audio_motion_avatar_amd.smplx_decoder import SMPLXDecoder
     from audio_motion_avatar_amd.synthetic import init_random_heads
 
     steps = {10000: 0, 30000: 1}.get(args.gaussians)
     if steps is None:
         raise SystemExit("--gaussians must be 10000 or 30000 (the reference's SUBDEVIDE_VERTS table)")
-    cfg = RendererConfig(image_size=(args.image, args.image), subdivide_steps=steps, predict_smplx_params=False,
-                         device=device)
-    return init_random_heads(Renderer(cfg).eval()), cfg
+    cfg = RendererConfig(image_size=(args.image, args.image), subdivide_steps=steps,
+                         predict_smplx_params=with_decoder, device=device)
+    dec = SMPLXDecoder(cfg).to(device) if with_decoder else None
+    return init_random_heads(Renderer(cfg, smpl_decoder=dec).eval()), cfg
+
+
+def run_full_workload(args, device, world, rank, dist):
+    """BASELINE configs[2]/[3]: every rank rolls its own 250-frame autoregressive chain from seeded tokens (segment
+    parallel, SURVEY.md section 8e option i), renders it and (N > 1) all-gathers the uint8 frames."""
+    from audio_motion_avatar_amd import ops
+    from audio_motion_avatar_amd.config import ModelConfig
+    from audio_motion_avatar_amd.dist import FrameAllGather
+    from audio_motion_avatar_amd.synthetic import make_render_inputs
+    from audio_motion_avatar_amd.triplane_audio_net import AudioTriplaneNet
+    import audio_motion_avatar_amd.renderer as R
+
+    renderer, rcfg = build_renderer(args, device, with_decoder=True)
+    mcfg = ModelConfig(renderer=rcfg)
+    torch.manual_seed(1234)  # random-init weights of the reference architecture (no checkpoint exists here)
+    net = AudioTriplaneNet(mcfg, renderer=renderer).to(device).eval()
+    with torch.no_grad():  # keep the 250-step autoregressive chain bounded, as a trained model's would be: each step
+        net.transformer.proj_out.weight.mul_(0.02)  # then perturbs the N(0,1) tokens instead of compounding them
+        net.transformer.proj_out.bias.zero_()
+    F, N, H, W = args.frames, args.gaussians, args.image, args.image
+    g = torch.Generator().manual_seed(42 + rank)
+    audio = torch.randn(1, F, 768, generator=g).to(device)
+    tri = torch.randn(1, 2, 256, 3 * 32 * 32, generator=g).to(device)
+    smpl_tok = (torch.randn(1, 2, 256, 80, generator=g) * 0.1).to(device)
+    _, _, cam = make_render_inputs(F, rcfg, seed=42 + rank, device=device)
+    workspace = ops.RasterWorkspace(F, N, H, W, ops.default_instance_capacity(F, N, 32), device)
+    gather = FrameAllGather(F, H, W, world, device) if world > 1 else None
+
+    def step():
+        with torch.no_grad():
+            out_tri, out_smpl = net.generate_tokens(audio, tri, smpl_tok, num_steps=F)
+            B, T = 1, F
+            params = renderer.smpl_decoder(out_smpl.reshape(T, 256, 80))
+            params = {k: v.reshape(B, T, *v.shape[1:]) for k, v in params.items()}
+            pts = renderer.get_smpl_vertices(params)
+            packed = renderer.decode_gaussians(out_tri[0], pts, params["transl"].reshape(T, 3))
+            rgba = R.render_batch(renderer.unpack_gaussians(packed), cam["intrinsic"], cam["extrinsic"], rcfg,
+                                  workspace=workspace, check_overflow=False, return_rgba=True)
+        if gather is not None:
+            gather.submit(rgba)
+        return rgba
+
+    step()  # sizes the rasterizer workspace (the only host sync of the path is this deferred overflow check)
+    total, max_frame, over = workspace.status_full()
+    if over:
+        workspace = ops.RasterWorkspace(F, N, H, W, int(F * max_frame * 1.25), device)
+    for _ in range(args.warmup):
+        step()
+    if gather is not None:
+        gather.wait()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rgba = step()
+    if gather is not None:
+        gather.wait()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    total, max_frame, over = workspace.status_full()
+    assert not over, "rasterizer workspace overflowed inside the timed region"
+    finite = bool(torch.isfinite(rgba).all())
+    result = {
+        "metric": "rendered frames/sec @512x512, 10k Gaussians (audio tokens -> AudioTriplaneNet -> SMPL-X LBS -> "
+                  "decode -> rasterize)",
+        "value": world * F * args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[2]: 250 synthetic audio tokens -> AudioTriplaneNet (8 layers, "
+                               "S=6304, autoregressive) -> SMPLXDecoder -> LBS -> decode -> rasterize 250 x 512x512",
+                   "frames_per_gpu_per_step": F, "gaussians": N, "image": [H, W], "weights": "random init (transformer.proj_out scaled by 0.02 so the AR chain stays bounded)",
+                   "instances_per_step": int(total), "output_finite": finite,
+                   "exchange": "all-gather of uint8 RGB frames over RCCL" if world > 1 else "none"},
+        "roofline": {"bound": "mfma", "kernel": "selfattn_kernel (fp32 MFMA flash attention)", "achieved": None,
+                     "peak": 157.3, "unit": "TFLOP/s", "frac": None, "traffic": None,
+                     "note": "see tools/bench_attention.py and profiles/ for the kernel-level number"},
+    }
+    if rank == 0:
+        print(json.dumps(result))
 
 
 def host_cores():
@@ -144,6 +235,12 @@ def main():
         import torch.distributed as dist
 
         dist.init_process_group("nccl", device_id=torch.device(device))
+
+    if args.workload == "full":
+        run_full_workload(args, device, world, rank, dist)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
     from audio_motion_avatar_amd import ops
     from audio_motion_avatar_amd.dist import FrameAllGather
