@@ -79,6 +79,9 @@ SIGNATURES = {
     "amav_triplane_sample_decode": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_float_p, c_float_p,
                                                    c_float_p, ctypes.c_float, c_float_p, c_float_p,
                                                    ctypes.c_void_p]),
+    "amav_triplane_sample_decode_indexed": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                           c_float_p, c_float_p, ctypes.c_void_p, c_float_p,
+                                                           ctypes.c_float, c_float_p, c_float_p, ctypes.c_void_p]),
     "amav_triplane_sample_features": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                      c_float_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                                      c_float_p, ctypes.c_float, c_float_p, ctypes.c_void_p]),

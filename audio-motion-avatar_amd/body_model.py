@@ -254,6 +254,8 @@ class BodyModel(torch.nn.Module):
         dirs = np.concatenate([arrays["shapedirs"], arrays["expr_dirs"]], axis=2).astype(np.float64)  # [V,3,NC]
         nc = dirs.shape[2]
         blend = np.concatenate([dirs.reshape(V * 3, nc).T, arrays["posedirs"].astype(np.float64)], axis=0)
+        kb = blend.shape[0]
+        blend = np.ascontiguousarray(blend.reshape(kb, V, 3).transpose(0, 2, 1))  # [KB, 3, V] component planes
         Jreg = arrays["J_regressor"].astype(np.float64)
         j_template = Jreg @ arrays["v_template"].astype(np.float64)                  # [J,3]
         j_dirs = np.einsum("jv,vcl->jcl", Jreg, dirs).reshape(J * 3, nc)            # [J*3, NC]

@@ -9,9 +9,10 @@
 //                       [betas; expression; (R_1..R_54 - I)] written TRANSPOSED ([k][frame]) so the skin kernel can
 //                       fetch 16 frames of one feature with a single scalar load.
 //   skin_kernel         one thread per vertex and FT frames: the [F, 506] x [506, 3V] blend product is done as
-//                       register-tiled FMAs whose frame operand is wave-uniform (SGPR), so the 63.6 MB blend table
-//                       is streamed once per FT frames, coalesced (12 B per lane); then T_v = sum_j w_vj A_j from
-//                       LDS and the 3x4 transform.  Nothing but the vertices is written.
+//                       register-tiled FMAs whose frame operand is wave-uniform (SGPR); the 63.6 MB blend table is
+//                       stored as component planes (coalesced rows) and the frame groups of a vertex chunk share an
+//                       XCD, so a chunk is fetched from HBM once; then T_v = sum_j w_vj A_j from LDS and the 3x4
+//                       transform.  Nothing but the vertices is written.
 //   gather_kernel       baked subdivision table -> the N sampled points.
 #include "amav_common.h"
 
@@ -127,13 +128,24 @@ __global__ __launch_bounds__(64) void joint_chain_kernel(Tables t, int F, int Fp
     }
 }
 
-// grid: (ceil(V/256), Fpad/FT).  featT rows are [k][Fpad]; A is [F][J][12].
+// grid: ceil(V/256) * (Fpad/FT) blocks.  featT rows are [k][Fpad]; A is [F][J][12]; blend is [KB][3][V] (component
+// planes, so a wave's loads are three fully coalesced 256-byte rows per k).
+// Block order: the frame groups of one vertex chunk are adjacent AND land on one XCD (blocks are dealt round-robin
+// over 8 XCDs), so each 1.5 MB chunk of the 64 MB blend table is fetched from HBM once and then re-read from that
+// XCD's L2 by the other frame groups (placement only affects speed).
 template <int FT>
-__global__ __launch_bounds__(256) void skin_kernel(Tables t, int F, int Fpad, const float *__restrict__ featT,
-                                                   const float *__restrict__ A, float *__restrict__ out) {
+__global__ __launch_bounds__(256) void skin_kernel(Tables t, int F, int Fpad, int nchunks,
+                                                   const float *__restrict__ featT, const float *__restrict__ A,
+                                                   float *__restrict__ out) {
     extern __shared__ __align__(16) float A_lds[];  // [FT][J][12]
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    const int f0 = blockIdx.y * FT;
+    const int ngroups = Fpad / FT;
+    // block id -> (chunk, frame group): ids of one XCD (id % 8) walk chunk-major over that XCD's share of the chunks
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int chunks_per_xcd = (nchunks + 7) / 8;
+    const int chunk = (j / ngroups) * 8 + xcd, fg = j % ngroups;
+    if (j / ngroups >= chunks_per_xcd || chunk >= nchunks) return;
+    const int v = chunk * blockDim.x + threadIdx.x;
+    const int f0 = fg * FT;
     const int nA = FT * t.J * 12;
     for (int k = threadIdx.x; k < nA; k += blockDim.x) {
         const int ff = f0 + k / (t.J * 12);
@@ -148,11 +160,11 @@ __global__ __launch_bounds__(256) void skin_kernel(Tables t, int F, int Fpad, co
 #pragma unroll
         for (int m = 0; m < FT; ++m) acc[m][0] = x, acc[m][1] = y, acc[m][2] = z;
     }
-    const float *bl = t.blend + (size_t)v * 3;
-    const size_t row = (size_t)t.V * 3;
-#pragma unroll 2
+    const float *bl = t.blend + v;
+    const size_t plane = (size_t)t.V, row = 3 * (size_t)t.V;
+#pragma unroll 4
     for (int k = 0; k < t.KB; ++k) {
-        const float b0 = bl[k * row], b1 = bl[k * row + 1], b2 = bl[k * row + 2];
+        const float b0 = bl[k * row], b1 = bl[k * row + plane], b2 = bl[k * row + 2 * plane];
         const float *fk = featT + (size_t)k * Fpad + f0;  // wave-uniform address -> scalar loads
 #pragma unroll
         for (int m = 0; m < FT; ++m) {
@@ -273,12 +285,13 @@ extern "C" int amav_lbs_forward(int F, const amav_body_tables *tb, const float *
         return fail(AMAV_ERR_LAUNCH, "amav_lbs_forward: hipMemsetAsync failed");
     float *A_dst = out_A ? out_A : A;
     joint_chain_kernel<<<F, 64, 0, stream>>>(t, F, Fpad, full_pose, coeffs, featT, A_dst);
-    const dim3 grid((t.V + 255) / 256, Fpad / FT);
+    const int nchunks = (t.V + 255) / 256;
+    const unsigned grid = (unsigned)(((nchunks + 7) / 8) * 8 * (Fpad / FT));
     const size_t lds = (size_t)FT * t.J * 12 * sizeof(float);
     if (FT == 4)
-        skin_kernel<4><<<grid, 256, lds, stream>>>(t, F, Fpad, featT, A_dst, out_vertices);
+        skin_kernel<4><<<grid, 256, lds, stream>>>(t, F, Fpad, nchunks, featT, A_dst, out_vertices);
     else
-        skin_kernel<16><<<grid, 256, lds, stream>>>(t, F, Fpad, featT, A_dst, out_vertices);
+        skin_kernel<16><<<grid, 256, lds, stream>>>(t, F, Fpad, nchunks, featT, A_dst, out_vertices);
     return check_launch("amav_lbs_forward");
 }
 

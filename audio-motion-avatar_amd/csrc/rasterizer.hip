@@ -42,8 +42,9 @@ constexpr int kBuckets = 17;  // list-length classes: bucket 0 = longer than 512
 __host__ __device__ inline int bucket_of(int n) { return n > 512 ? 0 : 16 - (n - 1) / 32; }
 
 struct Status {
-    long long total;      // sum over frames of (tile, Gaussian) instances
-    long long max_frame;  // largest per-frame instance count
+    long long total;      // sum over frames of (tile, Gaussian) instances as upstream counts them (3-sigma rectangles)
+    long long max_frame;  // largest per-frame count of EMITTED instances (what the instance regions must hold)
+    long long emitted;    // instances actually binned: rectangle tiles that the alpha >= 1/255 box can reach
     int overflow;         // some frame exceeded its region
     int big_count;        // tiles queued for sort_big
     // work lists of the blend kernel: per XCD queue, bucketed by list length (bucket 0 = longest)
@@ -116,7 +117,7 @@ __device__ __forceinline__ void wave_sync() {
 // /, sqrt are correctly rounded on both sides, so depth keys, radii and tile rectangles -- the decisions that move
 // whole Gaussians between tiles or swap their blend order -- come out bit-identical to the CPU restatement.
 __device__ __forceinline__ uint4 preprocess_one(const Params &p, int f, int i, const float *vm, const float *pm,
-                                                float tanx, float tany) {
+                                                float tanx, float tany, int &upstream_tiles) {
 #pragma clang fp contract(off)
     const size_t gi = (size_t)f * p.N + i;
     uint4 rd = make_uint4(0u, 0u, 0u, 0u);
@@ -219,7 +220,18 @@ __device__ __forceinline__ uint4 preprocess_one(const Params &p, int f, int i, c
         bx = sqrtf(tau * ca) * 1.001f + 0.01f;
         by = sqrtf(tau * cc) * 1.001f + 0.01f;
     }
-    rd = make_uint4((unsigned)rx0 | ((unsigned)ry0 << 16), (unsigned)rx1 | ((unsigned)ry1 << 16), __float_as_uint(vz),
+    upstream_tiles = (rx1 - rx0) * (ry1 - ry0);
+    // bin only the tiles of the 3-sigma rectangle that the alpha box reaches: in the others every pixel is rejected
+    // (alpha < 1/255), so dropping them changes nothing but the list lengths
+    int cx0 = 1, cx1 = 0, cy0 = 1, cy1 = 0;
+    if (tau > 0.0f) {
+        cx0 = max(rx0, (int)floorf((pix_x - bx) / (float)kTile));
+        cx1 = min(rx1, (int)floorf((pix_x + bx) / (float)kTile) + 1);
+        cy0 = max(ry0, (int)floorf((pix_y - by) / (float)kTile));
+        cy1 = min(ry1, (int)floorf((pix_y + by) / (float)kTile) + 1);
+    }
+    if (cx1 <= cx0 || cy1 <= cy0) cx0 = cx1 = cy0 = cy1 = 0;
+    rd = make_uint4((unsigned)cx0 | ((unsigned)cy0 << 16), (unsigned)cx1 | ((unsigned)cy1 << 16), __float_as_uint(vz),
                     (unsigned)(int)my_radius);
     float4 *g = p.buf.geom + gi * 3;
     // the conic is stored pre-multiplied by log2(e): the blend evaluates exp2 directly
@@ -266,8 +278,11 @@ __global__ __launch_bounds__(1024) void bin_kernel(Params p) {
     const float *pm = p.proj + f * 16;
     const float tanx = p.tanfov[2 * f], tany = p.tanfov[2 * f + 1];
     // phase 1: preprocess, count instances per tile (LDS atomics)
+    int upstream = 0;
     for (int i = threadIdx.x; i < p.N; i += blockDim.x) {
-        const uint4 rd = preprocess_one(p, f, i, vm, pm, tanx, tany);
+        int up = 0;
+        const uint4 rd = preprocess_one(p, f, i, vm, pm, tanx, tany, up);
+        upstream += up;
         const size_t gi = (size_t)f * p.N + i;
         p.buf.rectd[gi] = rd;
         if (p.out_radii) p.out_radii[gi] = (int)rd.w;
@@ -285,7 +300,8 @@ __global__ __launch_bounds__(1024) void bin_kernel(Params p) {
     int local = 0;
     for (int k = 0; k < per; ++k)
         if (t0 + k < p.T) local += counts[t0 + k];
-    int total;
+    int total, upstream_total;
+    block_exclusive_scan(upstream, scratch, &upstream_total);
     int run = block_exclusive_scan(local, scratch, &total);
     int *off = p.buf.tile_off + (size_t)f * (p.T + 1);
     for (int k = 0; k < per; ++k) {
@@ -333,7 +349,8 @@ __global__ __launch_bounds__(1024) void bin_kernel(Params p) {
         }
     if (threadIdx.x == 0) {
         off[p.T] = total;
-        atomicAdd(reinterpret_cast<unsigned long long *>(&p.buf.status->total), (unsigned long long)total);
+        atomicAdd(reinterpret_cast<unsigned long long *>(&p.buf.status->total), (unsigned long long)upstream_total);
+        atomicAdd(reinterpret_cast<unsigned long long *>(&p.buf.status->emitted), (unsigned long long)total);
         atomicMax(reinterpret_cast<unsigned long long *>(&p.buf.status->max_frame), (unsigned long long)total);
         if (!fits) atomicExch(&p.buf.status->overflow, 1);
     }
@@ -460,16 +477,17 @@ template <bool kInvDepth>
 __device__ __forceinline__ void blend_px(float power2, float op, float cr, float cg, float cb, float invd, float &T,
                                          float &Cr, float &Cg, float &Cb, float &Dp) {
     const float alpha = fminf(0.99f, op * __builtin_amdgcn_exp2f(power2));
+    const float w0 = alpha * T;
+    const float test_T = T - w0;  // = T (1 - alpha) up to one rounding
     const bool valid = (power2 <= 0.0f) & (alpha >= (1.0f / 255.0f)) & (T > 0.0f);
-    const float test_T = T * (1.0f - alpha);
     const bool fin = valid & (test_T < 0.0001f);
-    const bool acc = valid & !fin;
-    const float w = acc ? alpha * T : 0.0f;
+    const float w = (valid & !fin) ? w0 : 0.0f;
     Cr = fmaf(cr, w, Cr);
     Cg = fmaf(cg, w, Cg);
     Cb = fmaf(cb, w, Cb);
     if (kInvDepth) Dp = fmaf(invd, w, Dp);
-    T = fin ? -T : (acc ? test_T : T);
+    T -= w;             // unchanged unless this Gaussian was blended
+    T = fin ? -T : T;   // finished: the saturating Gaussian is not blended, the sign marks the pixel done
 }
 
 #define AMAV_STAMP(slot)                                                                              \

@@ -18,6 +18,8 @@
 namespace amav {
 namespace triplane {
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 // grid: (ceil(R*R/4 / 256), 3, F); each thread projects 4 consecutive texels of one plane.
 __global__ __launch_bounds__(256) void project_kernel(int C, int RR, const float *__restrict__ tokens,
                                                       long long frame_stride, const float *__restrict__ wplane,
@@ -33,9 +35,10 @@ __global__ __launch_bounds__(256) void project_kernel(int C, int RR, const float
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int o = 0; o < 16; ++o) acc[t][o] = 0.0f;
-#pragma unroll 4
+#pragma unroll 8
     for (int c = 0; c < C; ++c) {
-        const float4 x = *reinterpret_cast<const float4 *>(src + (size_t)c * S);
+        // read-once stream: non-temporal so the slab does not evict the projected planes / weights from L2
+        const f32x4 x = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(src + (size_t)c * S));
         const float *wc = w + c * 16;
 #pragma unroll
         for (int o = 0; o < 16; ++o) {
@@ -97,16 +100,31 @@ __device__ __forceinline__ Taps make_taps(float gx, float gy, int R) {
 
 // grid: (ceil(4N/256), F).  Lane group of 4 per point; lane q owns projected channels 4q..4q+3:
 //   q0 = (xyz_offset, opacity), q1 = rotation, q2 = (scaling, pad), q3 = (shs, pad)
-__global__ __launch_bounds__(256) void sample_decode_kernel(int N, int R, const float *__restrict__ proj,
+// kIndexed: the point is gathered from the posed vertices through the baked subdivision table (lbs.hip gather_kernel
+// fused in: 1/2 (1/2 (v[a0]+v[b0]) + 1/2 (v[a1]+v[b1])), the same operation order, so the same bits).
+template <bool kIndexed>
+__global__ __launch_bounds__(256) void sample_decode_kernel(int N, int R, int V, const float *__restrict__ proj,
                                                             const float *__restrict__ points,
-                                                            const float *__restrict__ transl, float radius, const float *__restrict__ wpoint,
+                                                            const int4 *__restrict__ idx4,
+                                                            const float *__restrict__ transl, float radius,
+                                                            const float *__restrict__ wpoint,
                                                             float *__restrict__ out) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int n = gid >> 2, q = gid & 3;
     const int f = blockIdx.y;
     if (n >= N) return;
-    const float *pp = points + ((size_t)f * N + n) * 3;
-    const float p0 = pp[0], p1 = pp[1], p2 = pp[2];
+    float p0, p1, p2;
+    if (kIndexed) {
+        const int4 id = idx4[n];
+        const float *vf = points + (size_t)f * V * 3;
+        const float *a0 = vf + id.x * 3, *b0 = vf + id.y * 3, *a1 = vf + id.z * 3, *b1 = vf + id.w * 3;
+        p0 = ((a0[0] + b0[0]) * 0.5f + (a1[0] + b1[0]) * 0.5f) * 0.5f;
+        p1 = ((a0[1] + b0[1]) * 0.5f + (a1[1] + b1[1]) * 0.5f) * 0.5f;
+        p2 = ((a0[2] + b0[2]) * 0.5f + (a1[2] + b1[2]) * 0.5f) * 0.5f;
+    } else {
+        const float *pp = points + ((size_t)f * N + n) * 3;
+        p0 = pp[0], p1 = pp[1], p2 = pp[2];
+    }
     const float u0 = fminf(fmaxf(p0 / radius, -1.0f), 1.0f);
     const float u1 = fminf(fmaxf(p1 / radius, -1.0f), 1.0f);
     const float u2 = fminf(fmaxf(p2 / radius, -1.0f), 1.0f);
@@ -223,9 +241,25 @@ extern "C" int amav_triplane_sample_decode(int F, int N, int R, const float *pro
                    reinterpret_cast<uintptr_t>(wpoint)) & 15) == 0,
                  "amav_triplane_sample_decode: proj/out/head_w_point not 16-B aligned");
     const dim3 grid((unsigned)(((size_t)N * 4 + 255) / 256), F);
-    sample_decode_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream_)>>>(N, R, proj, points, transl, radius,
-                                                                             wpoint, out);
+    sample_decode_kernel<false><<<grid, 256, 0, static_cast<hipStream_t>(stream_)>>>(N, R, 0, proj, points, nullptr,
+                                                                                    transl, radius, wpoint, out);
     return check_launch("amav_triplane_sample_decode");
+}
+
+extern "C" int amav_triplane_sample_decode_indexed(int F, int N, int R, int V, const float *proj,
+                                                   const float *vertices, const int32_t *idx4, const float *transl,
+                                                   float radius, const float *wpoint, float *out, void *stream_) {
+    AMAV_REQUIRE(F > 0 && N > 0 && R > 0 && V > 0, "amav_triplane_sample_decode_indexed: bad sizes");
+    AMAV_REQUIRE(F <= 65535, "amav_triplane_sample_decode_indexed: F=%d exceeds grid.y", F);
+    AMAV_REQUIRE(proj && vertices && idx4 && wpoint && out, "amav_triplane_sample_decode_indexed: NULL pointer");
+    AMAV_REQUIRE(radius > 0.0f, "amav_triplane_sample_decode_indexed: radius must be positive");
+    AMAV_REQUIRE(((reinterpret_cast<uintptr_t>(proj) | reinterpret_cast<uintptr_t>(out) |
+                   reinterpret_cast<uintptr_t>(wpoint) | reinterpret_cast<uintptr_t>(idx4)) & 15) == 0,
+                 "amav_triplane_sample_decode_indexed: proj/out/head_w_point/idx not 16-B aligned");
+    const dim3 grid((unsigned)(((size_t)N * 4 + 255) / 256), F);
+    sample_decode_kernel<true><<<grid, 256, 0, static_cast<hipStream_t>(stream_)>>>(
+        N, R, V, proj, vertices, reinterpret_cast<const int4 *>(idx4), transl, radius, wpoint, out);
+    return check_launch("amav_triplane_sample_decode_indexed");
 }
 
 extern "C" int amav_triplane_sample_features(int F, int N, int C, int R, const float *planes, int64_t frame_stride,

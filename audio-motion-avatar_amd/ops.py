@@ -320,6 +320,27 @@ def triplane_sample_decode(proj, points, transl, radius, head_w_point):
     return out
 
 
+def triplane_sample_decode_indexed(proj, vertices, idx4, transl, radius, head_w_point):
+    """triplane_sample_decode with points_gather fused in: vertices [F,V,3] + idx4 [N,4] instead of points."""
+    proj = _contig(proj, "proj")
+    vertices = _contig(vertices, "vertices")
+    idx4 = _contig(idx4, "idx4", torch.int32)
+    head_w_point = _contig(head_w_point, "head_w_point")
+    F, _, R, _, _ = proj.shape
+    if vertices.shape[0] != F:
+        raise AmavError(f"vertices has {vertices.shape[0]} frames, proj has {F}")
+    V, N = vertices.shape[1], idx4.shape[0]
+    if transl is not None:
+        transl = _contig(transl.reshape(F, 3), "transl")
+    out = torch.empty(F, N, GAUSS_STRIDE, device=proj.device)
+    check(_lib.lib().amav_triplane_sample_decode_indexed(F, N, R, V, proj.data_ptr(), vertices.data_ptr(),
+                                                         idx4.data_ptr(),
+                                                         transl.data_ptr() if transl is not None else None,
+                                                         float(radius), head_w_point.data_ptr(), out.data_ptr(),
+                                                         _stream()), "amav_triplane_sample_decode_indexed")
+    return out
+
+
 def triplane_sample_features(planes, points, radius):
     """planes [F,3,C,R,R] (any strides with unit stride along W and R along H), points [F,N,3] -> [F,N,3C]."""
     _need(planes, "planes")

@@ -65,6 +65,7 @@ class Renderer(nn.Module):
         nn.init.constant_(self.gaussian_decoder.scaling_layer.bias, -1.0)
         nn.init.constant_(self.gaussian_decoder.opacity_layer.bias, inverse_sigmoid(0.1))
         self._packed = None
+        self._side_stream = None
         self.to(cfg.device)
 
     # ---- body model ------------------------------------------------------------------------------------------
@@ -85,15 +86,17 @@ class Renderer(nn.Module):
         self.subset_index = idx  # ids into the densified vertex list (kept for tests)
         self.register_buffer("_gather_idx", torch.as_tensor(table)[idx].contiguous(), persistent=False)
 
-    def get_smpl_vertices(self, smpl_params):
-        """renderer.py:245-290: SMPL-X LBS for all B*T frames, then densify + subset.  -> [B*T, N, 3]"""
+    def _posed_vertices(self, smpl_params):
         B, T = smpl_params["global_orient"].shape[:2]
         r = lambda k: smpl_params[k].reshape(B * T, -1)
-        output = self.smplx_model(global_orient=r("global_orient"), body_pose=r("body_pose"), betas=r("betas"),
-                                  left_hand_pose=r("left_hand_pose"), right_hand_pose=r("right_hand_pose"),
-                                  jaw_pose=r("jaw_pose"), leye_pose=r("leye_pose"), reye_pose=r("reye_pose"),
-                                  expression=r("expression"))
-        vertices = output.vertices
+        return self.smplx_model(global_orient=r("global_orient"), body_pose=r("body_pose"), betas=r("betas"),
+                                left_hand_pose=r("left_hand_pose"), right_hand_pose=r("right_hand_pose"),
+                                jaw_pose=r("jaw_pose"), leye_pose=r("leye_pose"), reye_pose=r("reye_pose"),
+                                expression=r("expression")).vertices
+
+    def get_smpl_vertices(self, smpl_params):
+        """renderer.py:245-290: SMPL-X LBS for all B*T frames, then densify + subset.  -> [B*T, N, 3]"""
+        vertices = self._posed_vertices(smpl_params)
         if self.cfg.densify_smplx_verts:
             vertices = ops.points_gather(vertices, self._gather_idx)
         return vertices
@@ -123,6 +126,31 @@ class Renderer(nn.Module):
         w_plane, w_point = self._head_weights()
         proj = ops.triplane_project(triplane_tokens, w_plane, self.cfg.triplane_resolution)
         return ops.triplane_sample_decode(proj, points, transl, self.cfg.radius, w_point)
+
+    def gaussians_from_tokens(self, triplane_tokens, smpl_params):
+        """renderer.py:127-181 as one fused stage: tokens [F,C,3R^2] + SMPL-X params -> packed Gaussians [F,N,16].
+
+        The triplane projection (HBM streaming) does not depend on the body model, so it runs on a side stream
+        while the LBS chain (latency/VALU bound) runs on the current one; the densify + subset gather is folded
+        into the sampling kernel.
+        """
+        F = triplane_tokens.shape[0]
+        w_plane, w_point = self._head_weights()
+        cur = torch.cuda.current_stream()
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=triplane_tokens.device)
+        side = self._side_stream
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            proj = ops.triplane_project(triplane_tokens, w_plane, self.cfg.triplane_resolution)
+        vertices = self._posed_vertices(smpl_params)
+        cur.wait_stream(side)
+        proj.record_stream(cur)
+        transl = smpl_params["transl"].reshape(F, 3).float()
+        if self.cfg.densify_smplx_verts:
+            return ops.triplane_sample_decode_indexed(proj, vertices, self._gather_idx, transl, self.cfg.radius,
+                                                      w_point)
+        return ops.triplane_sample_decode(proj, vertices, transl, self.cfg.radius, w_point)
 
     @staticmethod
     def unpack_gaussians(packed):
@@ -161,8 +189,7 @@ class Renderer(nn.Module):
         if smpl_params is None:
             raise AmavError("Renderer.forward: no SMPL-X parameters (predict_smplx_params is off and no smpl_params_gt)")
 
-        points = self.get_smpl_vertices(smpl_params)  # [B*T, N, 3]
-        packed = self.decode_gaussians(tokens, points, smpl_params["transl"].reshape(B * T, 3).float())
+        packed = self.gaussians_from_tokens(tokens, smpl_params)  # LBS + densify + fused triplane decode
         gaussians = self.unpack_gaussians(packed)
         rendered_images = render_batch(gaussians, cam_params["intrinsic"], cam_params["extrinsic"], self.cfg)
         if self.cfg.predict_smplx_params:

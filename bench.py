@@ -85,7 +85,7 @@ def run_full_workload(args, device, world, rank, dist):
     smpl_tok = (torch.randn(1, 2, 256, 80, generator=g) * 0.1).to(device)
     _, _, cam = make_render_inputs(F, rcfg, seed=42 + rank, device=device)
     workspace = ops.RasterWorkspace(F, N, H, W, ops.default_instance_capacity(F, N, 32), device)
-    gather = FrameAllGather(F, H, W, world, device) if world > 1 else None
+    gather = FrameAllGather(F, H, W, world, device) if dist is not None else None
 
     def step():
         with torch.no_grad():
@@ -93,8 +93,7 @@ def run_full_workload(args, device, world, rank, dist):
             B, T = 1, F
             params = renderer.smpl_decoder(out_smpl.reshape(T, 256, 80))
             params = {k: v.reshape(B, T, *v.shape[1:]) for k, v in params.items()}
-            pts = renderer.get_smpl_vertices(params)
-            packed = renderer.decode_gaussians(out_tri[0], pts, params["transl"].reshape(T, 3))
+            packed = renderer.gaussians_from_tokens(out_tri[0], params)
             rgba = R.render_batch(renderer.unpack_gaussians(packed), cam["intrinsic"], cam["extrinsic"], rcfg,
                                   workspace=workspace, check_overflow=False, return_rgba=True)
         if gather is not None:
@@ -190,8 +189,10 @@ def cpu_baseline_and_parity(renderer, cfg, tokens, smpl, cam, step_outputs, n_fr
     sec = sorted(times)[1]
 
     # stage-by-stage parity on identical inputs
-    gpu_pts, gpu_packed, gpu_rgba = (t[:n_frames].cpu() for t in step_outputs)
+    gpu_packed, gpu_rgba = (t[:n_frames].cpu() for t in step_outputs)
     gpu_g = renderer.unpack_gaussians(gpu_packed)
+    with torch.no_grad():  # the unfused product entry point of the same stage (Renderer.get_smpl_vertices)
+        gpu_pts = renderer.get_smpl_vertices({k: v[:, :n_frames] for k, v in smpl.items()}).cpu()
     g_on_gpu_pts = o_tri.decode_gaussians(params, planes, gpu_pts, sp["transl"].reshape(-1, 3), cfg.radius)
     ref_img, ref_alpha, ref_unstable = o_rast.render_batch({k: v.contiguous() for k, v in gpu_g.items()}, K, E,
                                                            cfg.image_size, full=True)
@@ -231,9 +232,12 @@ def main():
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
     dist = None
-    if world > 1:
+    force_exchange = os.environ.get("AMAV_BENCH_FORCE_EXCHANGE") == "1"  # rehearse the N > 1 path on one GPU
+    if world > 1 or force_exchange:
         import torch.distributed as dist
 
+        if force_exchange and "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=torch.device(device))
 
     if args.workload == "full":
@@ -251,21 +255,20 @@ def main():
     tokens, smpl, cam = make_render_inputs(F, cfg, seed=42 + rank, device=device)
     smpl_tokens = torch.zeros(1, F, 1, 1, device=device)  # only its [B,T] shape is read when no decoder is attached
     workspace = ops.RasterWorkspace(F, N, H, W, ops.default_instance_capacity(F, N), device)
-    gather = FrameAllGather(F, H, W, world, device) if world > 1 else None
+    gather = FrameAllGather(F, H, W, world, device) if dist is not None else None
 
     import audio_motion_avatar_amd.renderer as R
 
-    stages = [None, None, None]  # the last step's intermediate tensors (parity check)
+    stages = [None, None]  # the last step's intermediate tensors (parity check)
 
     def step():
         # the body of Renderer.forward (renderer.py:73-204) with the rasterizer workspace pinned and its overflow
         # check (the only host sync) deferred to the end of the run; returns the RGBA buffer [1,F,H,W,4]
-        pts = renderer.get_smpl_vertices(smpl)
-        packed = renderer.decode_gaussians(tokens[0], pts, smpl["transl"].reshape(F, 3))
+        packed = renderer.gaussians_from_tokens(tokens[0], smpl)
         g = renderer.unpack_gaussians(packed)
         rgba = R.render_batch(g, cam["intrinsic"], cam["extrinsic"], cfg, workspace=workspace, check_overflow=False,
                               return_rgba=True)
-        stages[:] = [pts, packed, rgba[0]]
+        stages[:] = [packed, rgba[0]]
         return rgba
 
     # one eager step: validates the drop-in entry point end to end and sizes the workspace
@@ -339,7 +342,7 @@ def main():
                                "no audio net", "frames_per_gpu_per_step": F, "gaussians": N, "image": [H, W],
                    "triplane": [cfg.triplane_feature_dim, cfg.triplane_resolution],
                    "instances_per_step": int(total),
-                   "exchange": "all-gather of uint8 RGB frames over RCCL" if world > 1 else "none"},
+                   "exchange": "all-gather of uint8 RGB frames over RCCL" if dist is not None else "none"},
         "roofline": {"bound": "hbm", "kernel": "render_kernel (tile blend)", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "avg_launch_ms": blend_avg_ms, "algorithmic_bytes_per_launch": blend_bytes},

@@ -128,8 +128,8 @@ int amav_frames_to_rgb8(int64_t num_pixels, const float *rgba_dev, uint8_t *out_
  * Replaces smplx.SMPLX.forward -> smplx.lbs.lbs as called at src/models/renderer.py:261-274 (no transl;
  * use_pca=False).  Model constants are immutable device tables prepared once by the host mirror
  * (audio-motion-avatar_amd/body_model.py) from the SMPL-X arrays:
- *   v_template [V,3]; blend [(n_coeff + (J-1)*9), V*3]: rows 0..n_coeff-1 = shape+expression directions,
- *   then posedirs; j_template [J,3] = J_regressor v_template; j_dirs [J*3, n_coeff] = J_regressor applied to
+ *   v_template [V,3]; blend [(n_coeff + (J-1)*9), 3, V] (x / y / z planes per row): rows 0..n_coeff-1 = shape +
+ *   expression directions, then posedirs; j_template [J,3] = J_regressor v_template; j_dirs [J*3, n_coeff] = J_regressor applied to
  *   the shape directions; parents [J]; skin_idx / skin_w [V, skin_k]: the non-zero LBS weights of each vertex in
  *   ascending joint order, padded with weight 0.
  */
@@ -181,6 +181,12 @@ int amav_triplane_project(int num_frames, int channels, int resolution, const fl
 int amav_triplane_sample_decode(int num_frames, int num_points, int resolution, const float *proj_dev,
                                 const float *points_dev, const float *transl_dev, float radius,
                                 const float *head_w_point_dev, float *out_gaussians_dev, void *stream);
+/* The same with amav_points_gather fused in: the N points are gathered from the posed vertices [F,V,3] through the
+ * baked subdivision table idx [N,4] (identical operation order, so identical bits), saving the [F,N,3] round trip. */
+int amav_triplane_sample_decode_indexed(int num_frames, int num_points, int resolution, int num_verts,
+                                        const float *proj_dev, const float *vertices_dev, const int32_t *idx_dev,
+                                        const float *transl_dev, float radius, const float *head_w_point_dev,
+                                        float *out_gaussians_dev, void *stream);
 /* Plain Renderer.sample_from_triplane (renderer.py:292-317): element (f,p,c,h,w) of the planes lives at
  * planes[f*frame_stride + p*plane_stride + c*chan_stride + h*R + w] (so both the [F,3,C,R,R] tensor and the
  * [F,C,(3 R R)] token layout are addressable); points [F,N,3] -> features [F,N,3C] in (plane, channel) order. */

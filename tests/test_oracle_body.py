@@ -115,7 +115,7 @@ def test_synthetic_body_is_smplx_shaped():
 
     b = body()
     assert b.num_verts == 10475 and b.num_joints == 55
-    assert b._blend.shape == (20 + 54 * 9, 10475 * 3)
+    assert b._blend.shape == (20 + 54 * 9, 3, 10475)
     assert np.array_equal(b.parents, SMPLX_PARENTS) and b.parents[0] == -1 and (b.parents[1:] < np.arange(1, 55)).all()
     w = b.lbs_weights
     assert torch.allclose(w.sum(1), torch.ones(10475), atol=1e-6) and (w >= 0).all()

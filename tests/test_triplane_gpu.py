@@ -57,3 +57,21 @@ def test_sample_features_matches_grid_sample(F, N, C, R):
     got = ops.triplane_sample_features(planes.cuda(), points.cuda(), 1.4).cpu()
     assert got.shape == ref.shape
     assert (got - ref).abs().max() <= 1e-5
+
+
+def test_indexed_decode_equals_gather_then_decode_bitwise():
+    """amav_triplane_sample_decode_indexed == amav_points_gather + amav_triplane_sample_decode, bit for bit."""
+    from audio_motion_avatar_amd import ops
+
+    F, V, N, C, R = 3, 500, 800, 32, 8
+    g = torch.Generator().manual_seed(4)
+    tokens, _, transl, params = make_case(9, F, N, C, R)
+    verts = (torch.randn(F, V, 3, generator=g) * 0.6).cuda()
+    idx = torch.randint(0, V, (N, 4), generator=g, dtype=torch.int32).cuda()
+    heads = {n: (params[f"gaussian_decoder.{n}.weight"], params[f"gaussian_decoder.{n}.bias"])
+             for n in ("xyz_layer", "rotation_layer", "scaling_layer", "opacity_layer", "shs_layer")}
+    w_plane, w_point = ops.pack_head_weights(heads, C, "cuda")
+    proj = ops.triplane_project(tokens.cuda(), w_plane, R)
+    a = ops.triplane_sample_decode(proj, ops.points_gather(verts, idx), transl.cuda(), 1.4, w_point)
+    b = ops.triplane_sample_decode_indexed(proj, verts, idx, transl.cuda(), 1.4, w_point)
+    assert torch.equal(a, b)
