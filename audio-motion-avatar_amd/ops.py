@@ -116,7 +116,7 @@ class RasterWorkspace:
         return total.value, mx.value, bool(over.value)
 
 
-# When set to an (Event, Event) pair, the next rasterize() call records it around its blend kernel (bench.py).
+# A list of (Event, Event) pairs: every rasterize() call pops one and records it around its blend kernel (bench.py).
 PROFILE_EVENTS = None
 # diagnostic: int64 CUDA tensor [F*tiles, 6] that receives the blend kernel's per-tile clock stamps (tools/)
 DEBUG_STAMPS = None
@@ -181,7 +181,9 @@ def rasterize(means3d, rotations, scales, opacities, colors, viewmatrix, projmat
         args.instance_capacity = ws.capacity
         if DEBUG_STAMPS is not None:
             args.debug_stamps = DEBUG_STAMPS.data_ptr()
-        ev = profile_events if profile_events is not None else PROFILE_EVENTS
+        ev = profile_events
+        if ev is None and PROFILE_EVENTS:
+            ev = PROFILE_EVENTS.pop(0)
         if ev is not None:
             args.profile_start_event, args.profile_stop_event = ev[0].handle, ev[1].handle
         check(_lib.lib().amav_rasterize_forward(ctypes.byref(args), _stream()), "amav_rasterize_forward")
@@ -301,7 +303,16 @@ def triplane_project(tokens, head_w_plane, resolution):
     return out
 
 
-def triplane_sample_decode(proj, points, transl, radius, head_w_point):
+def _decode_out(out, F, N, device):
+    if out is None:
+        return torch.empty(F, N, GAUSS_STRIDE, device=device)
+    _need(out, "out")
+    if tuple(out.shape) != (F, N, GAUSS_STRIDE) or not out.is_contiguous():
+        raise AmavError(f"out must be contiguous {(F, N, GAUSS_STRIDE)}, got {tuple(out.shape)}")
+    return out
+
+
+def triplane_sample_decode(proj, points, transl, radius, head_w_point, out=None):
     """proj [F,3,R,R,16], points [F,N,3], transl [F,3] | None -> packed Gaussians [F,N,16]."""
     proj = _contig(proj, "proj")
     points = _contig(points, "points")
@@ -312,7 +323,7 @@ def triplane_sample_decode(proj, points, transl, radius, head_w_point):
         raise AmavError(f"points has {points.shape[0]} frames, proj has {F}")
     if transl is not None:
         transl = _contig(transl.reshape(F, 3), "transl")
-    out = torch.empty(F, N, GAUSS_STRIDE, device=proj.device)
+    out = _decode_out(out, F, N, proj.device)
     check(_lib.lib().amav_triplane_sample_decode(F, N, R, proj.data_ptr(), points.data_ptr(),
                                                  transl.data_ptr() if transl is not None else None, float(radius),
                                                  head_w_point.data_ptr(), out.data_ptr(), _stream()),
@@ -320,7 +331,7 @@ def triplane_sample_decode(proj, points, transl, radius, head_w_point):
     return out
 
 
-def triplane_sample_decode_indexed(proj, vertices, idx4, transl, radius, head_w_point):
+def triplane_sample_decode_indexed(proj, vertices, idx4, transl, radius, head_w_point, out=None):
     """triplane_sample_decode with points_gather fused in: vertices [F,V,3] + idx4 [N,4] instead of points."""
     proj = _contig(proj, "proj")
     vertices = _contig(vertices, "vertices")
@@ -332,7 +343,7 @@ def triplane_sample_decode_indexed(proj, vertices, idx4, transl, radius, head_w_
     V, N = vertices.shape[1], idx4.shape[0]
     if transl is not None:
         transl = _contig(transl.reshape(F, 3), "transl")
-    out = torch.empty(F, N, GAUSS_STRIDE, device=proj.device)
+    out = _decode_out(out, F, N, proj.device)
     check(_lib.lib().amav_triplane_sample_decode_indexed(F, N, R, V, proj.data_ptr(), vertices.data_ptr(),
                                                          idx4.data_ptr(),
                                                          transl.data_ptr() if transl is not None else None,

@@ -66,6 +66,7 @@ class Renderer(nn.Module):
         nn.init.constant_(self.gaussian_decoder.opacity_layer.bias, inverse_sigmoid(0.1))
         self._packed = None
         self._side_stream = None
+        self._chunk_streams = []
         self.to(cfg.device)
 
     # ---- body model ------------------------------------------------------------------------------------------
@@ -127,7 +128,7 @@ class Renderer(nn.Module):
         proj = ops.triplane_project(triplane_tokens, w_plane, self.cfg.triplane_resolution)
         return ops.triplane_sample_decode(proj, points, transl, self.cfg.radius, w_point)
 
-    def gaussians_from_tokens(self, triplane_tokens, smpl_params):
+    def gaussians_from_tokens(self, triplane_tokens, smpl_params, out=None):
         """renderer.py:127-181 as one fused stage: tokens [F,C,3R^2] + SMPL-X params -> packed Gaussians [F,N,16].
 
         The triplane projection (HBM streaming) does not depend on the body model, so it runs on a side stream
@@ -138,8 +139,10 @@ class Renderer(nn.Module):
         w_plane, w_point = self._head_weights()
         cur = torch.cuda.current_stream()
         if self._side_stream is None:
-            self._side_stream = torch.cuda.Stream(device=triplane_tokens.device)
-        side = self._side_stream
+            self._side_stream = {}
+        side = self._side_stream.get(cur.cuda_stream)
+        if side is None:  # one helper stream per calling stream (render_tokens runs chunks on several)
+            side = self._side_stream[cur.cuda_stream] = torch.cuda.Stream(device=triplane_tokens.device)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             proj = ops.triplane_project(triplane_tokens, w_plane, self.cfg.triplane_resolution)
@@ -149,8 +152,53 @@ class Renderer(nn.Module):
         transl = smpl_params["transl"].reshape(F, 3).float()
         if self.cfg.densify_smplx_verts:
             return ops.triplane_sample_decode_indexed(proj, vertices, self._gather_idx, transl, self.cfg.radius,
-                                                      w_point)
-        return ops.triplane_sample_decode(proj, vertices, transl, self.cfg.radius, w_point)
+                                                      w_point, out=out)
+        return ops.triplane_sample_decode(proj, vertices, transl, self.cfg.radius, w_point, out=out)
+
+    def render_tokens(self, triplane_tokens, smpl_params, cam_params, chunks=1, workspaces=None, check_overflow=True,
+                      bg_color=None):
+        """tokens [F,C,3R^2] + SMPL-X params [B,T,...] (B*T = F) + cameras -> (rgba [F,H,W,4], packed [F,N,16]).
+
+        The body of forward() after the SMPL-X decoder.  With `chunks` > 1 the frames are split into that many
+        groups, each driven on its own HIP stream: the blend kernel is VALU-bound while LBS / projection / binning
+        are memory- and latency-bound, so one group's rasterisation overlaps the next group's decode.
+        `workspaces`: optional list of per-chunk RasterWorkspace objects (reused across calls; resized entries are
+        written back).  With check_overflow=False the caller must check workspaces[i].status() itself.
+        """
+        F = triplane_tokens.shape[0]
+        H, W = int(self.cfg.image_size[0]), int(self.cfg.image_size[1])
+        flat = {k: v.reshape(F, *v.shape[2:]) for k, v in smpl_params.items()}
+        K = cam_params["intrinsic"].reshape(F, 3, 3)
+        E = cam_params["extrinsic"].reshape(F, 4, 4)
+        chunks = max(1, min(int(chunks), F))
+        bounds = [(F * i // chunks, F * (i + 1) // chunks) for i in range(chunks)]
+        dev = triplane_tokens.device
+        rgba = torch.empty(F, H, W, 4, device=dev)
+        packed_all = torch.empty(F, self.num_verts if self.cfg.densify_smplx_verts else self.smplx_model.num_verts,
+                                 ops.GAUSS_STRIDE, device=dev)
+        if workspaces is None:
+            workspaces = [None] * chunks
+        cur = torch.cuda.current_stream()
+        while len(self._chunk_streams) < chunks - 1:
+            self._chunk_streams.append(torch.cuda.Stream(device=dev))
+        used = []
+        for ci, (s, e) in enumerate(bounds):
+            st = cur if ci == 0 else self._chunk_streams[ci - 1]
+            if st is not cur:
+                st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                sub = {k: v[s:e].unsqueeze(0) for k, v in flat.items()}
+                packed = self.gaussians_from_tokens(triplane_tokens[s:e], sub, out=packed_all[s:e])
+                g = self.unpack_gaussians(packed)
+                out = render_batch(g, K[s:e].unsqueeze(0), E[s:e].unsqueeze(0), self.cfg, bg_color,
+                                   workspace=workspaces[ci], check_overflow=check_overflow, out_rgba=rgba[s:e],
+                                   return_workspace=True)
+                workspaces[ci] = out[1]
+            used.append(st)
+        for st in used:
+            if st is not cur:
+                cur.wait_stream(st)
+        return rgba, packed_all
 
     @staticmethod
     def unpack_gaussians(packed):
@@ -189,9 +237,10 @@ class Renderer(nn.Module):
         if smpl_params is None:
             raise AmavError("Renderer.forward: no SMPL-X parameters (predict_smplx_params is off and no smpl_params_gt)")
 
-        packed = self.gaussians_from_tokens(tokens, smpl_params)  # LBS + densify + fused triplane decode
+        chunks = int(getattr(self.cfg, "pipeline_chunks", 1)) if B * T >= 32 else 1
+        rgba, packed = self.render_tokens(tokens, smpl_params, cam_params, chunks=chunks)
         gaussians = self.unpack_gaussians(packed)
-        rendered_images = render_batch(gaussians, cam_params["intrinsic"], cam_params["extrinsic"], self.cfg)
+        rendered_images = rgba.view(B, T, *rgba.shape[1:])[..., :3]
         if self.cfg.predict_smplx_params:
             return rendered_images, gaussians, pred_smpl_params
         return rendered_images, gaussians
@@ -217,7 +266,7 @@ def render_multi_view(gaussians, K, E, args, bg_color=None, debug=False):
 
 
 def render_batch(gaussians, K, E, args, bg_color=None, debug=False, return_alpha=False, workspace=None,
-                 check_overflow=True, return_rgba=False):
+                 check_overflow=True, return_rgba=False, out_rgba=None, return_workspace=False):
     """renderer.py:447-479: gaussians dict [(B*T),N,*], K [B,T,3,3], E [B,T,4,4] -> images [B,T,H,W,3] in [0,1].
 
     One camera launch + one rasterizer launch sequence for all B*T frames.  The returned image is a view of the
@@ -242,8 +291,10 @@ def render_batch(gaussians, K, E, args, bg_color=None, debug=False, return_alpha
         color = color.clamp(0.0, 1.0)
         activate = False
     out = ops.rasterize(xyz, rot, scale, opacity, color, view, proj, tanfov, H, W, bg=bg, apply_activations=activate,
-                        clamp_output=True, workspace=workspace, check_overflow=check_overflow)
+                        clamp_output=True, workspace=workspace, check_overflow=check_overflow, out_rgba=out_rgba)
     rgba = out["rgba"].view(B, T, H, W, 4)
+    if return_workspace:
+        return rgba, out["workspace"]
     if return_rgba:
         return rgba
     if return_alpha:

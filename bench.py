@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--image", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the workload timed on the CPU oracle")
+    ap.add_argument("--chunks", type=int, default=1,
+                    help="frame groups pipelined on separate HIP streams (1 is fastest: 2 -> +17 %, 4 -> +56 % time)")
     ap.add_argument("--workload", choices=["render", "full"], default="render",
                     help="render = BASELINE configs[1] (static decode + LBS + rasterize, the metric's config); "
                          "full = configs[2]: synthetic audio tokens -> AudioTriplaneNet (autoregressive) -> SMPL-X "
@@ -84,7 +86,7 @@ def run_full_workload(args, device, world, rank, dist):
     tri = torch.randn(1, 2, 256, 3 * 32 * 32, generator=g).to(device)
     smpl_tok = (torch.randn(1, 2, 256, 80, generator=g) * 0.1).to(device)
     _, _, cam = make_render_inputs(F, rcfg, seed=42 + rank, device=device)
-    workspace = ops.RasterWorkspace(F, N, H, W, ops.default_instance_capacity(F, N, 32), device)
+    workspaces = [None] * max(1, min(args.chunks, F))
     gather = FrameAllGather(F, H, W, world, device) if dist is not None else None
 
     def step():
@@ -93,17 +95,18 @@ def run_full_workload(args, device, world, rank, dist):
             B, T = 1, F
             params = renderer.smpl_decoder(out_smpl.reshape(T, 256, 80))
             params = {k: v.reshape(B, T, *v.shape[1:]) for k, v in params.items()}
-            packed = renderer.gaussians_from_tokens(out_tri[0], params)
-            rgba = R.render_batch(renderer.unpack_gaussians(packed), cam["intrinsic"], cam["extrinsic"], rcfg,
-                                  workspace=workspace, check_overflow=False, return_rgba=True)
+            rgba, _ = renderer.render_tokens(out_tri[0], params, cam, chunks=args.chunks, workspaces=workspaces,
+                                             check_overflow=False)
         if gather is not None:
             gather.submit(rgba)
         return rgba
 
-    step()  # sizes the rasterizer workspace (the only host sync of the path is this deferred overflow check)
-    total, max_frame, over = workspace.status_full()
-    if over:
-        workspace = ops.RasterWorkspace(F, N, H, W, int(F * max_frame * 1.25), device)
+    step()  # sizes the rasterizer workspaces (the only host sync of the path is this deferred overflow check)
+    for ci, ws in enumerate(workspaces):
+        _, max_frame, over = ws.status_full()
+        if over:
+            fc, n, h, w = ws.key
+            workspaces[ci] = ops.RasterWorkspace(fc, n, h, w, int(fc * max_frame * 1.25), device)
     for _ in range(args.warmup):
         step()
     if gather is not None:
@@ -124,8 +127,9 @@ def run_full_workload(args, device, world, rank, dist):
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    total, max_frame, over = workspace.status_full()
-    assert not over, "rasterizer workspace overflowed inside the timed region"
+    status = [ws.status() for ws in workspaces]
+    total = sum(s[0] for s in status)
+    assert not any(s[1] for s in status), "rasterizer workspace overflowed inside the timed region"
     finite = bool(torch.isfinite(rgba).all())
     result = {
         "metric": "rendered frames/sec @512x512, 10k Gaussians (audio tokens -> AudioTriplaneNet -> SMPL-X LBS -> "
@@ -254,7 +258,7 @@ def main():
     F, N, H, W = args.frames, args.gaussians, args.image, args.image
     tokens, smpl, cam = make_render_inputs(F, cfg, seed=42 + rank, device=device)
     smpl_tokens = torch.zeros(1, F, 1, 1, device=device)  # only its [B,T] shape is read when no decoder is attached
-    workspace = ops.RasterWorkspace(F, N, H, W, ops.default_instance_capacity(F, N), device)
+    workspaces = [None] * max(1, min(args.chunks, F))  # filled by the first step, then reused
     gather = FrameAllGather(F, H, W, world, device) if dist is not None else None
 
     import audio_motion_avatar_amd.renderer as R
@@ -264,31 +268,31 @@ def main():
     def step():
         # the body of Renderer.forward (renderer.py:73-204) with the rasterizer workspace pinned and its overflow
         # check (the only host sync) deferred to the end of the run; returns the RGBA buffer [1,F,H,W,4]
-        packed = renderer.gaussians_from_tokens(tokens[0], smpl)
-        g = renderer.unpack_gaussians(packed)
-        rgba = R.render_batch(g, cam["intrinsic"], cam["extrinsic"], cfg, workspace=workspace, check_overflow=False,
-                              return_rgba=True)
-        stages[:] = [packed, rgba[0]]
-        return rgba
+        rgba, packed = renderer.render_tokens(tokens[0], smpl, cam, chunks=args.chunks, workspaces=workspaces,
+                                              check_overflow=False)
+        stages[:] = [packed, rgba]
+        return rgba.unsqueeze(0)
 
     # one eager step: validates the drop-in entry point end to end and sizes the workspace
     with torch.no_grad():
         ref_img = renderer(tokens, cam, smpl_tokens, smpl)[0]
         rgba = step()
         torch.cuda.synchronize()
-        total, max_frame, over = workspace.status_full()
-        if over:
-            workspace = ops.RasterWorkspace(F, N, H, W, int(F * max_frame * 1.25), device)
-            rgba = step()
-            total, max_frame, over = workspace.status_full()
-        assert not over
+        for ci, ws in enumerate(workspaces):
+            _, max_frame, over = ws.status_full()
+            if over:
+                fc, n, h, w = ws.key
+                workspaces[ci] = ops.RasterWorkspace(fc, n, h, w, int(fc * max_frame * 1.25), device)
+        rgba = step()
+        assert not any(ws.status()[1] for ws in workspaces)
         assert torch.equal(ref_img, rgba[..., :3]), "pinned-workspace step differs from Renderer.forward"
         del ref_img, rgba
 
-    events = [(ops.Event(), ops.Event()) for _ in range(args.steps)]
+    nchunks = len(workspaces)
+    events = [[(ops.Event(), ops.Event()) for _ in range(nchunks)] for _ in range(args.steps)]
 
     def timed_step(i):
-        ops.PROFILE_EVENTS = events[i] if i is not None else None
+        ops.PROFILE_EVENTS = list(events[i]) if i is not None else None
         with torch.no_grad():
             out = step()
         if gather is not None:
@@ -316,10 +320,12 @@ def main():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    total, over = workspace.status()
-    assert not over, "rasterizer workspace overflowed inside the timed region"
+    status = [ws.status() for ws in workspaces]
+    total = sum(s[0] for s in status)
+    assert not any(s[1] for s in status), "rasterizer workspace overflowed inside the timed region"
 
-    blend_ms = sorted(s.elapsed_ms(e) for s, e in events)
+    # blend-kernel time per step = sum over the step's frame groups (one launch each)
+    blend_ms = sorted(sum(s.elapsed_ms(e) for s, e in step_events) for step_events in events)
     blend_avg_ms = sum(blend_ms) / len(blend_ms)
     # algorithmic bytes of the blend kernel per frame: RGBA out (16 B/px) + one 40 B record per Gaussian
     # (xy, conic, opacity, rgb, depth), each moved once (DESIGN.md "kernels")
@@ -341,7 +347,7 @@ def main():
         "config": {"workload": "BASELINE configs[1]: 512x512, 10k Gaussians, static triplane decode + LBS + rasterize, "
                                "no audio net", "frames_per_gpu_per_step": F, "gaussians": N, "image": [H, W],
                    "triplane": [cfg.triplane_feature_dim, cfg.triplane_resolution],
-                   "instances_per_step": int(total),
+                   "instances_per_step": int(total), "stream_pipelined_frame_groups": len(workspaces),
                    "exchange": "all-gather of uint8 RGB frames over RCCL" if dist is not None else "none"},
         "roofline": {"bound": "hbm", "kernel": "render_kernel (tile blend)", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
