@@ -11,9 +11,11 @@
 //   skin_kernel         one thread per vertex and FT frames: the [F, 506] x [506, 3V] blend product is done as
 //                       register-tiled FMAs whose frame operand is wave-uniform (SGPR); the 63.6 MB blend table is
 //                       stored as component planes (coalesced rows) and the frame groups of a vertex chunk share an
-//                       XCD, so a chunk is fetched from HBM once; then T_v = sum_j w_vj A_j from LDS and the 3x4
-//                       transform.  Nothing but the vertices is written.
+//                       XCD, so a chunk is fetched from HBM once; the group's feature slice sits in LDS; then
+//                       T_v = sum_j w_vj A_j and the 3x4 transform.  Nothing but the vertices is written.
 //   gather_kernel       baked subdivision table -> the N sampled points.
+#include <cstdlib>
+
 #include "amav_common.h"
 
 namespace amav {
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(64) void joint_chain_kernel(Tables t, int F, int Fp
     }
 }
 
-// grid: ceil(V/256) * (Fpad/FT) blocks.  featT rows are [k][Fpad]; A is [F][J][12]; blend is [KB][3][V] (component
+// grid: ceil(V/256) * (Fpad/FT) blocks.  featT rows are [k][Fpad]; A is [Fpad][J][12]; blend is [KB][3][V] (component
 // planes, so a wave's loads are three fully coalesced 256-byte rows per k).
 // Block order: the frame groups of one vertex chunk are adjacent AND land on one XCD (blocks are dealt round-robin
 // over 8 XCDs), so each 1.5 MB chunk of the 64 MB blend table is fetched from HBM once and then re-read from that
@@ -137,7 +139,7 @@ template <int FT>
 __global__ __launch_bounds__(256) void skin_kernel(Tables t, int F, int Fpad, int nchunks,
                                                    const float *__restrict__ featT, const float *__restrict__ A,
                                                    float *__restrict__ out) {
-    extern __shared__ __align__(16) float A_lds[];  // [FT][J][12]
+    extern __shared__ __align__(16) float feat_lds[];  // [KB][FT]: this frame group's slice of the feature matrix
     const int ngroups = Fpad / FT;
     // block id -> (chunk, frame group): ids of one XCD (id % 8) walk chunk-major over that XCD's share of the chunks
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
@@ -146,11 +148,10 @@ __global__ __launch_bounds__(256) void skin_kernel(Tables t, int F, int Fpad, in
     if (j / ngroups >= chunks_per_xcd || chunk >= nchunks) return;
     const int v = chunk * blockDim.x + threadIdx.x;
     const int f0 = fg * FT;
-    const int nA = FT * t.J * 12;
-    for (int k = threadIdx.x; k < nA; k += blockDim.x) {
-        const int ff = f0 + k / (t.J * 12);
-        A_lds[k] = ff < F ? A[(size_t)f0 * t.J * 12 + k] : 0.0f;
-    }
+    // stage the group's features once: the k-loop then reads them as LDS broadcasts (scalar loads of a 32 KB slice
+    // per block thrash the scalar cache and put an L2 round trip into every iteration)
+    for (int k = threadIdx.x; k < t.KB * FT; k += blockDim.x)
+        feat_lds[k] = featT[(size_t)(k / FT) * Fpad + f0 + (k % FT)];
     __syncthreads();
     if (v >= t.V) return;
 
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(256) void skin_kernel(Tables t, int F, int Fpad, in
 #pragma unroll 4
     for (int k = 0; k < t.KB; ++k) {
         const float b0 = bl[k * row], b1 = bl[k * row + plane], b2 = bl[k * row + 2 * plane];
-        const float *fk = featT + (size_t)k * Fpad + f0;  // wave-uniform address -> scalar loads
+        const float *fk = feat_lds + k * FT;  // same address in every lane: LDS broadcast
 #pragma unroll
         for (int m = 0; m < FT; ++m) {
             const float s = fk[m];
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(256) void skin_kernel(Tables t, int F, int Fpad, in
         float Tm[12];
 #pragma unroll
         for (int e = 0; e < 12; ++e) Tm[e] = 0.0f;
-        const float *Af = A_lds + m * t.J * 12;
+        const float *Af = A + (size_t)(f0 + m) * t.J * 12;  // 3 x 16 B per (frame, joint), L1/L2 resident
         auto add = [&](int ji, float w) {
             const float4 *a4 = reinterpret_cast<const float4 *>(Af + ji * 12);
             const float4 r0 = a4[0], r1 = a4[1], r2 = a4[2];
@@ -226,7 +227,11 @@ __global__ __launch_bounds__(256) void gather_kernel(int V, int N, const float *
     }
 }
 
-static int frame_tile(int F) { return F <= 8 ? 4 : 16; }
+static int frame_tile(int F) {
+    static const int forced = getenv("AMAV_LBS_FT") ? atoi(getenv("AMAV_LBS_FT")) : 0;  // tuning aid: 4, 8, 16 or 32
+    if (forced == 4 || forced == 8 || forced == 16 || forced == 32) return forced;
+    return F <= 8 ? 4 : 16;
+}
 
 }  // namespace lbs
 }  // namespace amav
@@ -287,9 +292,13 @@ extern "C" int amav_lbs_forward(int F, const amav_body_tables *tb, const float *
     joint_chain_kernel<<<F, 64, 0, stream>>>(t, F, Fpad, full_pose, coeffs, featT, A_dst);
     const int nchunks = (t.V + 255) / 256;
     const unsigned grid = (unsigned)(((nchunks + 7) / 8) * 8 * (Fpad / FT));
-    const size_t lds = (size_t)FT * t.J * 12 * sizeof(float);
+    const size_t lds = (size_t)FT * t.KB * sizeof(float);
     if (FT == 4)
         skin_kernel<4><<<grid, 256, lds, stream>>>(t, F, Fpad, nchunks, featT, A_dst, out_vertices);
+    else if (FT == 8)
+        skin_kernel<8><<<grid, 256, lds, stream>>>(t, F, Fpad, nchunks, featT, A_dst, out_vertices);
+    else if (FT == 32)
+        skin_kernel<32><<<grid, 256, lds, stream>>>(t, F, Fpad, nchunks, featT, A_dst, out_vertices);
     else
         skin_kernel<16><<<grid, 256, lds, stream>>>(t, F, Fpad, nchunks, featT, A_dst, out_vertices);
     return check_launch("amav_lbs_forward");

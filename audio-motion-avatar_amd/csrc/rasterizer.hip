@@ -116,13 +116,26 @@ __device__ __forceinline__ void wave_sync() {
 // One Gaussian of frame f.  Contraction is off and the operation order is the oracle's (oracle/raster_ref.c): +, *,
 // /, sqrt are correctly rounded on both sides, so depth keys, radii and tile rectangles -- the decisions that move
 // whole Gaussians between tiles or swap their blend order -- come out bit-identical to the CPU restatement.
+template <bool kPacked>
 __device__ __forceinline__ uint4 preprocess_one(const Params &p, int f, int i, const float *vm, const float *pm,
                                                 float tanx, float tany, int &upstream_tiles) {
 #pragma clang fp contract(off)
     const size_t gi = (size_t)f * p.N + i;
     uint4 rd = make_uint4(0u, 0u, 0u, 0u);
-    const float *m = at(p.means3d, f, i);
-    const float px3 = m[0], py3 = m[1], pz3 = m[2];
+    // kPacked: the five attributes are views of one packed [.., 16] record (triplane.hip layout): four 16-byte loads
+    float4 rec0, rec1, rec2, rec3;
+    if (kPacked) {
+        const float4 *rec = reinterpret_cast<const float4 *>(at(p.means3d, f, i));
+        rec0 = rec[0], rec1 = rec[1], rec2 = rec[2], rec3 = rec[3];
+    } else {
+        const float *m_ = at(p.means3d, f, i), *q_ = at(p.rotations, f, i), *s_ = at(p.scales, f, i);
+        const float *c_ = at(p.colors, f, i);
+        rec0 = make_float4(m_[0], m_[1], m_[2], at(p.opacities, f, i)[0]);
+        rec1 = make_float4(q_[0], q_[1], q_[2], q_[3]);
+        rec2 = make_float4(s_[0], s_[1], s_[2], 0.f);
+        rec3 = make_float4(c_[0], c_[1], c_[2], 0.f);
+    }
+    const float px3 = rec0.x, py3 = rec0.y, pz3 = rec0.z;
     const float vx = vm[0] * px3 + vm[4] * py3 + vm[8] * pz3 + vm[12];
     const float vy = vm[1] * px3 + vm[5] * py3 + vm[9] * pz3 + vm[13];
     const float vz = vm[2] * px3 + vm[6] * py3 + vm[10] * pz3 + vm[14];
@@ -133,13 +146,10 @@ __device__ __forceinline__ uint4 preprocess_one(const Params &p, int f, int i, c
     const float pw = 1.0f / (hw + 0.0000001f);
     const float ppx = hx_ * pw, ppy = hy_ * pw;
 
-    const float *q = at(p.rotations, f, i);
-    const float r = q[0], x = q[1], y = q[2], z = q[3];
-    const float *sc = at(p.scales, f, i);
-    float s0 = sc[0], s1 = sc[1], s2 = sc[2];
-    float opacity = at(p.opacities, f, i)[0];
-    const float *cl = at(p.colors, f, i);
-    float c0 = cl[0], c1 = cl[1], c2 = cl[2];
+    const float r = rec1.x, x = rec1.y, y = rec1.z, z = rec1.w;
+    float s0 = rec2.x, s1 = rec2.y, s2 = rec2.z;
+    float opacity = rec0.w;
+    float c0 = rec3.x, c1 = rec3.y, c2 = rec3.z;
     if (p.apply_activations) {
         s0 = fminf(expf(s0 - p.scale_bias), p.scale_max);
         s1 = fminf(expf(s1 - p.scale_bias), p.scale_max);
@@ -265,6 +275,7 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int *lds_wave, int *t
 }
 
 // grid = F blocks of 1024 threads; dynamic LDS = (2*T + 16 + 3*(kBuckets+1)) ints: counts[T], cursor[T], scratch, classes
+template <bool kPacked>
 __global__ __launch_bounds__(1024) void bin_kernel(Params p) {
     extern __shared__ int bin_lds[];
     int *counts = bin_lds;
@@ -281,7 +292,7 @@ __global__ __launch_bounds__(1024) void bin_kernel(Params p) {
     int upstream = 0;
     for (int i = threadIdx.x; i < p.N; i += blockDim.x) {
         int up = 0;
-        const uint4 rd = preprocess_one(p, f, i, vm, pm, tanx, tany, up);
+        const uint4 rd = preprocess_one<kPacked>(p, f, i, vm, pm, tanx, tany, up);
         upstream += up;
         const size_t gi = (size_t)f * p.N + i;
         p.buf.rectd[gi] = rd;
@@ -437,6 +448,8 @@ __global__ __launch_bounds__(256) void sort_big_kernel(Params p) {
 }
 
 // --------------------------------------------------------------------------------------------------------- render
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 struct WaveLds {
     unsigned long long keys[kSortCap];  // keys, then (in place) the blend order as 32-bit Gaussian ids
     float4 stage[3][64];
@@ -531,6 +544,7 @@ __device__ __forceinline__ void render_tile(const Params &p, WaveLds &L, int ite
     float pxf0 = (float)(X0 + lx), pxf1 = (float)(X0 + 8 + lx);
     float pyf0 = (float)(Y0 + ly), pyf1 = (float)(Y0 + 8 + ly);
     asm volatile("" : "+v"(pxf0), "+v"(pxf1), "+v"(pyf0), "+v"(pyf1));  // keep them in registers (no re-convert)
+    const f32x2 pxp = {pxf0, pxf1}, pyp = {pyf0, pyf1};
     const bool in0 = X0 + lx < p.W, in1 = X0 + 8 + lx < p.W, inr0 = Y0 + ly < p.H, inr1 = Y0 + 8 + ly < p.H;
 
     float T0 = (in0 & inr0) ? 1.f : -1.f, T1 = (in1 & inr0) ? 1.f : -1.f;
@@ -605,14 +619,14 @@ __device__ __forceinline__ void render_tile(const Params &p, WaveLds &L, int ite
                 const float4 an = L.stage[0][jn], bn = L.stage[1][jn], cn = L.stage[2][jn];
                 const int m = __builtin_amdgcn_readfirstlane(__float_as_int(c.z)) & qalive;
                 if (m) {
-                    const float dx0 = a.x - pxf0, dx1 = a.x - pxf1, dy0 = a.y - pyf0, dy1 = a.y - pyf1;
-                    const float ax0 = a.z * dx0 * dx0, ax1 = a.z * dx1 * dx1;
-                    const float cy0 = bq.x * dy0 * dy0, cy1 = bq.x * dy1 * dy1;
-                    const float bx0 = a.w * dx0, bx1 = a.w * dx1;
-                    if (m & 1) blend_px<kInvDepth>(-0.5f * (ax0 + cy0) - bx0 * dy0, bq.y, bq.z, bq.w, c.x, c.y, T0, R0, G0, B0, D0);
-                    if (m & 2) blend_px<kInvDepth>(-0.5f * (ax1 + cy0) - bx1 * dy0, bq.y, bq.z, bq.w, c.x, c.y, T1, R1, G1, B1, D1);
-                    if (m & 4) blend_px<kInvDepth>(-0.5f * (ax0 + cy1) - bx0 * dy1, bq.y, bq.z, bq.w, c.x, c.y, T2, R2, G2, B2, D2);
-                    if (m & 8) blend_px<kInvDepth>(-0.5f * (ax1 + cy1) - bx1 * dy1, bq.y, bq.z, bq.w, c.x, c.y, T3, R3, G3, B3, D3);
+                    // the two columns / two rows of this lane's pixels as packed fp32 pairs (v_pk_*_f32: both halves
+                    // in one issue slot; per element the same IEEE operations as the scalar form)
+                    const f32x2 dx = a.x - pxp, dy = a.y - pyp;
+                    const f32x2 ax = (a.z * dx) * dx, cy = (bq.x * dy) * dy, bx = a.w * dx;
+                    if (m & 1) blend_px<kInvDepth>(-0.5f * (ax.x + cy.x) - bx.x * dy.x, bq.y, bq.z, bq.w, c.x, c.y, T0, R0, G0, B0, D0);
+                    if (m & 2) blend_px<kInvDepth>(-0.5f * (ax.y + cy.x) - bx.y * dy.x, bq.y, bq.z, bq.w, c.x, c.y, T1, R1, G1, B1, D1);
+                    if (m & 4) blend_px<kInvDepth>(-0.5f * (ax.x + cy.y) - bx.x * dy.y, bq.y, bq.z, bq.w, c.x, c.y, T2, R2, G2, B2, D2);
+                    if (m & 8) blend_px<kInvDepth>(-0.5f * (ax.y + cy.y) - bx.y * dy.y, bq.y, bq.z, bq.w, c.x, c.y, T3, R3, G3, B3, D3);
                 }
                 if ((j & 7) == 7) {  // a quadrant whose 64 pixels are all finished takes no further Gaussians
                     qalive = (__any(T0 > 0.f) ? 1 : 0) | (__any(T1 > 0.f) ? 2 : 0) | (__any(T2 > 0.f) ? 4 : 0) |
@@ -741,13 +755,30 @@ extern "C" int amav_rasterize_forward(const amav_raster_args *a, void *stream_) 
     p.stamps = static_cast<unsigned long long *>(a->debug_stamps);
 
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&bin_kernel),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (attr != hipSuccess) return fail(AMAV_ERR_LAUNCH, "amav_rasterize_forward: cannot raise the dynamic LDS limit");
+    static const hipError_t attr[2] = {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&bin_kernel<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&bin_kernel<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)};
+    if (attr[0] != hipSuccess || attr[1] != hipSuccess)
+        return fail(AMAV_ERR_LAUNCH, "amav_rasterize_forward: cannot raise the dynamic LDS limit");
+    // packed-record fast path: the attributes are the xyz|opacity|rot|scale|color views of one [.., 16] buffer
+    const float *b0 = a->means3d.ptr;
+    const bool packed = (reinterpret_cast<uintptr_t>(b0) & 15) == 0 && a->means3d.elem_stride == 16 &&
+                        a->means3d.frame_stride % 4 == 0 && a->opacities.ptr == b0 + 3 && a->rotations.ptr == b0 + 4 &&
+                        a->scales.ptr == b0 + 8 && a->colors.ptr == b0 + 12 && a->opacities.elem_stride == 16 &&
+                        a->rotations.elem_stride == 16 && a->scales.elem_stride == 16 && a->colors.elem_stride == 16 &&
+                        a->opacities.frame_stride == a->means3d.frame_stride &&
+                        a->rotations.frame_stride == a->means3d.frame_stride &&
+                        a->scales.frame_stride == a->means3d.frame_stride &&
+                        a->colors.frame_stride == a->means3d.frame_stride;
     if (hipMemsetAsync(p.buf.status, 0, sizeof(Status), stream) != hipSuccess)
         return fail(AMAV_ERR_LAUNCH, "amav_rasterize_forward: hipMemsetAsync failed");
 
-    bin_kernel<<<F, 1024, bin_lds, stream>>>(p);
+    if (packed)
+        bin_kernel<true><<<F, 1024, bin_lds, stream>>>(p);
+    else
+        bin_kernel<false><<<F, 1024, bin_lds, stream>>>(p);
     sort_big_kernel<<<kBigBlocks, 256, 0, stream>>>(p);
     // worst-case grid (every tile non-empty in one queue); must be a multiple of kQueues
     const long long per_queue = ((long long)p.qcap + 3) / 4;

@@ -98,20 +98,26 @@ __device__ __forceinline__ Taps make_taps(float gx, float gy, int R) {
     return t;
 }
 
-// grid: (ceil(4N/256), F).  Lane group of 4 per point; lane q owns projected channels 4q..4q+3:
+// Lane group of 4 per point; lane q owns projected channels 4q..4q+3:
 //   q0 = (xyz_offset, opacity), q1 = rotation, q2 = (scaling, pad), q3 = (shs, pad)
 // kIndexed: the point is gathered from the posed vertices through the baked subdivision table (lbs.hip gather_kernel
 // fused in: 1/2 (1/2 (v[a0]+v[b0]) + 1/2 (v[a1]+v[b1])), the same operation order, so the same bits).
 template <bool kIndexed>
-__global__ __launch_bounds__(256) void sample_decode_kernel(int N, int R, int V, const float *__restrict__ proj,
+__global__ __launch_bounds__(256) void sample_decode_kernel(int F, int N, int R, int V,
+                                                            const float *__restrict__ proj,
                                                             const float *__restrict__ points,
                                                             const int4 *__restrict__ idx4,
                                                             const float *__restrict__ transl, float radius,
                                                             const float *__restrict__ wpoint,
                                                             float *__restrict__ out) {
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    // 1-D grid, frames grouped per XCD: blocks are dealt round-robin over the 8 XCDs, so block b serves frame
+    // (b/8 / bpf) * 8 + b%8 and one XCD's L2 keeps a frame's 196 KB of projected planes to itself (speed only)
+    const int bpf = (4 * N + 255) / 256;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int f = (j / bpf) * 8 + xcd;
+    if (f >= F) return;
+    const int gid = (j % bpf) * blockDim.x + threadIdx.x;
     const int n = gid >> 2, q = gid & 3;
-    const int f = blockIdx.y;
     if (n >= N) return;
     float p0, p1, p2;
     if (kIndexed) {
@@ -240,8 +246,8 @@ extern "C" int amav_triplane_sample_decode(int F, int N, int R, const float *pro
     AMAV_REQUIRE(((reinterpret_cast<uintptr_t>(proj) | reinterpret_cast<uintptr_t>(out) |
                    reinterpret_cast<uintptr_t>(wpoint)) & 15) == 0,
                  "amav_triplane_sample_decode: proj/out/head_w_point not 16-B aligned");
-    const dim3 grid((unsigned)(((size_t)N * 4 + 255) / 256), F);
-    sample_decode_kernel<false><<<grid, 256, 0, static_cast<hipStream_t>(stream_)>>>(N, R, 0, proj, points, nullptr,
+    const unsigned grid = (unsigned)(((size_t)N * 4 + 255) / 256) * 8u * (unsigned)((F + 7) / 8);
+    sample_decode_kernel<false><<<grid, 256, 0, static_cast<hipStream_t>(stream_)>>>(F, N, R, 0, proj, points, nullptr,
                                                                                     transl, radius, wpoint, out);
     return check_launch("amav_triplane_sample_decode");
 }
@@ -256,9 +262,9 @@ extern "C" int amav_triplane_sample_decode_indexed(int F, int N, int R, int V, c
     AMAV_REQUIRE(((reinterpret_cast<uintptr_t>(proj) | reinterpret_cast<uintptr_t>(out) |
                    reinterpret_cast<uintptr_t>(wpoint) | reinterpret_cast<uintptr_t>(idx4)) & 15) == 0,
                  "amav_triplane_sample_decode_indexed: proj/out/head_w_point/idx not 16-B aligned");
-    const dim3 grid((unsigned)(((size_t)N * 4 + 255) / 256), F);
+    const unsigned grid = (unsigned)(((size_t)N * 4 + 255) / 256) * 8u * (unsigned)((F + 7) / 8);
     sample_decode_kernel<true><<<grid, 256, 0, static_cast<hipStream_t>(stream_)>>>(
-        N, R, V, proj, vertices, reinterpret_cast<const int4 *>(idx4), transl, radius, wpoint, out);
+        F, N, R, V, proj, vertices, reinterpret_cast<const int4 *>(idx4), transl, radius, wpoint, out);
     return check_launch("amav_triplane_sample_decode_indexed");
 }
 

@@ -128,12 +128,13 @@ class Renderer(nn.Module):
         proj = ops.triplane_project(triplane_tokens, w_plane, self.cfg.triplane_resolution)
         return ops.triplane_sample_decode(proj, points, transl, self.cfg.radius, w_point)
 
-    def gaussians_from_tokens(self, triplane_tokens, smpl_params, out=None):
+    def gaussians_from_tokens(self, triplane_tokens, smpl_params, out=None, side_work=None):
         """renderer.py:127-181 as one fused stage: tokens [F,C,3R^2] + SMPL-X params -> packed Gaussians [F,N,16].
 
         The triplane projection (HBM streaming) does not depend on the body model, so it runs on a side stream
         while the LBS chain (latency/VALU bound) runs on the current one; the densify + subset gather is folded
-        into the sampling kernel.
+        into the sampling kernel.  `side_work`: optional callable run on the side stream after the projection (the
+        camera kernel rides there, off the critical path); its result is returned as a second value.
         """
         F = triplane_tokens.shape[0]
         w_plane, w_point = self._head_weights()
@@ -144,16 +145,25 @@ class Renderer(nn.Module):
         if side is None:  # one helper stream per calling stream (render_tokens runs chunks on several)
             side = self._side_stream[cur.cuda_stream] = torch.cuda.Stream(device=triplane_tokens.device)
         side.wait_stream(cur)
+        side_result = None
         with torch.cuda.stream(side):
             proj = ops.triplane_project(triplane_tokens, w_plane, self.cfg.triplane_resolution)
+            if side_work is not None:
+                side_result = side_work()
         vertices = self._posed_vertices(smpl_params)
         cur.wait_stream(side)
-        proj.record_stream(cur)
+        proj.record_stream(cur)  # made on the helper stream, consumed (and later freed) on this one
+        if isinstance(side_result, (tuple, list)):
+            for t_ in side_result:
+                if isinstance(t_, torch.Tensor):
+                    t_.record_stream(cur)
         transl = smpl_params["transl"].reshape(F, 3).float()
         if self.cfg.densify_smplx_verts:
-            return ops.triplane_sample_decode_indexed(proj, vertices, self._gather_idx, transl, self.cfg.radius,
-                                                      w_point, out=out)
-        return ops.triplane_sample_decode(proj, vertices, transl, self.cfg.radius, w_point, out=out)
+            packed = ops.triplane_sample_decode_indexed(proj, vertices, self._gather_idx, transl, self.cfg.radius,
+                                                        w_point, out=out)
+        else:
+            packed = ops.triplane_sample_decode(proj, vertices, transl, self.cfg.radius, w_point, out=out)
+        return packed if side_work is None else (packed, side_result)
 
     def render_tokens(self, triplane_tokens, smpl_params, cam_params, chunks=1, workspaces=None, check_overflow=True,
                       bg_color=None):
@@ -188,11 +198,14 @@ class Renderer(nn.Module):
                 st.wait_stream(cur)
             with torch.cuda.stream(st):
                 sub = {k: v[s:e].unsqueeze(0) for k, v in flat.items()}
-                packed = self.gaussians_from_tokens(triplane_tokens[s:e], sub, out=packed_all[s:e])
+                Kc, Ec = K[s:e].float(), E[s:e].float()
+                packed, camera = self.gaussians_from_tokens(
+                    triplane_tokens[s:e], sub, out=packed_all[s:e],
+                    side_work=lambda: ops.camera_from_intrinsics(Kc, Ec, H, W))
                 g = self.unpack_gaussians(packed)
                 out = render_batch(g, K[s:e].unsqueeze(0), E[s:e].unsqueeze(0), self.cfg, bg_color,
                                    workspace=workspaces[ci], check_overflow=check_overflow, out_rgba=rgba[s:e],
-                                   return_workspace=True)
+                                   return_workspace=True, camera=camera[:3])
                 workspaces[ci] = out[1]
             used.append(st)
         for st in used:
@@ -248,6 +261,7 @@ class Renderer(nn.Module):
 
 ### Gaussian Splatting Renderer ###
 
+
 def _flat(t, width):
     return t.reshape(-1, t.shape[-2], width).float()
 
@@ -266,7 +280,7 @@ def render_multi_view(gaussians, K, E, args, bg_color=None, debug=False):
 
 
 def render_batch(gaussians, K, E, args, bg_color=None, debug=False, return_alpha=False, workspace=None,
-                 check_overflow=True, return_rgba=False, out_rgba=None, return_workspace=False):
+                 check_overflow=True, return_rgba=False, out_rgba=None, return_workspace=False, camera=None):
     """renderer.py:447-479: gaussians dict [(B*T),N,*], K [B,T,3,3], E [B,T,4,4] -> images [B,T,H,W,3] in [0,1].
 
     One camera launch + one rasterizer launch sequence for all B*T frames.  The returned image is a view of the
@@ -278,7 +292,10 @@ def render_batch(gaussians, K, E, args, bg_color=None, debug=False, return_alpha
                                   "cannot run with 3-channel colours (SURVEY.md Appendix C.4)")
     B, T = E.shape[0], E.shape[1]
     H, W = int(args.image_size[0]), int(args.image_size[1])
-    view, proj, tanfov, _ = ops.camera_from_intrinsics(K.reshape(-1, 3, 3).float(), E.reshape(-1, 4, 4).float(), H, W)
+    if camera is None:
+        view, proj, tanfov, _ = ops.camera_from_intrinsics(K.reshape(-1, 3, 3).float(), E.reshape(-1, 4, 4).float(), H, W)
+    else:  # (viewmatrix, projmatrix, tanfov) already built from these K / E
+        view, proj, tanfov = camera
     xyz, rot = _flat(gaussians["xyz"], 3), _flat(gaussians["rot"], 4)
     scale, opacity, color = _flat(gaussians["scale"], 3), _flat(gaussians["opacity"], 1), _flat(gaussians["color"], 3)
     if xyz.shape[0] != B * T:

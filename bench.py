@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the workload timed on the CPU oracle")
     ap.add_argument("--chunks", type=int, default=1,
-                    help="frame groups pipelined on separate HIP streams (1 is fastest: 2 -> +17 %, 4 -> +56 % time)")
+                    help="frame groups pipelined on separate HIP streams (1 is fastest; 2 costs 17 percent more time, 4 costs 56 percent)")
     ap.add_argument("--workload", choices=["render", "full"], default="render",
                     help="render = BASELINE configs[1] (static decode + LBS + rasterize, the metric's config); "
                          "full = configs[2]: synthetic audio tokens -> AudioTriplaneNet (autoregressive) -> SMPL-X "
