@@ -85,9 +85,10 @@ SIGNATURES = {
     "amav_triplane_sample_features": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                      c_float_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                                      c_float_p, ctypes.c_float, c_float_p, ctypes.c_void_p]),
+    "amav_selfattn_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "amav_selfattn_forward": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_float_p,
                                              c_float_p, c_float_p, ctypes.c_int64, c_float_p, ctypes.c_int64,
-                                             ctypes.c_float, ctypes.c_void_p]),
+                                             ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
 }
 
 _lib = None

@@ -26,16 +26,20 @@ constexpr int kBM = 128;      // queries per workgroup (4 waves x 32)
 constexpr int kBN = 64;       // keys per tile
 constexpr int kLdk = kBN + 1; // padded row of the transposed K tile
 
+// nsplit > 1: the key range is cut into nsplit slices handled by different workgroups (finer tasks balance the
+// 1576 wave-tasks of the reference shape over 1024 SIMDs); each slice writes its un-normalised O, running max and
+// sum to `part`, and combine_kernel merges them.
 __global__ __launch_bounds__(256) void selfattn_kernel(const float *__restrict__ q, const float *__restrict__ k,
                                                        const float *__restrict__ v, float *__restrict__ out, int S,
                                                        long long row_stride, long long out_row_stride,
-                                                       float scale_log2e) {
+                                                       float scale_log2e, int nsplit, float *__restrict__ part) {
     __shared__ float Kt[kD * kLdk];   // [d][key]
     __shared__ float Vs[kBN * kD];    // [key][d]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int c = lane & 31, hh = lane >> 5;
     const int head = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * kBM + wave * 32;
+    const int split = blockIdx.x % nsplit;
+    const int q0 = (blockIdx.x / nsplit) * kBM + wave * 32;
     const size_t base = (size_t)b * S;
 
     // Q fragment (B operand of S^T = K Q^T): Q[q0 + c][2 s + hh], pre-scaled by softmax_scale * log2(e)
@@ -75,9 +79,11 @@ __global__ __launch_bounds__(256) void selfattn_kernel(const float *__restrict__
         Kt[(sd + 3) * kLdk + key_] = kr_.w;                           \
         *reinterpret_cast<float4 *>(&Vs[key_ * kD + sd]) = vr_;      \
     }
-    const int ntiles = (S + kBN - 1) / kBN;
-    AMAV_LOAD_TILE(0)
-    for (int kt = 0; kt < ntiles; ++kt) {
+    const int ntiles_all = (S + kBN - 1) / kBN;
+    const int kt_begin = (int)((long long)ntiles_all * split / nsplit);
+    const int ntiles = (int)((long long)ntiles_all * (split + 1) / nsplit);  // end of this slice
+    AMAV_LOAD_TILE(kt_begin)
+    for (int kt = kt_begin; kt < ntiles; ++kt) {
         // ---- stage tile kt (K transposed, V as is)
         AMAV_STAGE_ONE(0, k0, v0) AMAV_STAGE_ONE(1, k1, v1) AMAV_STAGE_ONE(2, k2, v2) AMAV_STAGE_ONE(3, k3, v3)
         __syncthreads();
@@ -143,6 +149,21 @@ __global__ __launch_bounds__(256) void selfattn_kernel(const float *__restrict__
     }
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    if (nsplit > 1) {
+        // partial record of (split, b, head, query): 64 un-normalised O values, then m and l
+        if (q0 + c < S) {
+            float *prow = part + ((((size_t)split * gridDim.z + b) * gridDim.y + head) * S + q0 + c) * (kD + 2);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = 8 * g + 4 * hh;
+                prow[d] = O0[4 * g], prow[d + 1] = O0[4 * g + 1], prow[d + 2] = O0[4 * g + 2], prow[d + 3] = O0[4 * g + 3];
+                prow[32 + d] = O1[4 * g], prow[33 + d] = O1[4 * g + 1], prow[34 + d] = O1[4 * g + 2];
+                prow[35 + d] = O1[4 * g + 3];
+            }
+            if (hh == 0) prow[kD] = m_run, prow[kD + 1] = l_tot;
+        }
+        return;
+    }
     const float inv = 1.0f / l_tot;
     if (q0 + c < S) {
         float *orow = out + (base + q0 + c) * out_row_stride + head * kD;
@@ -157,14 +178,70 @@ __global__ __launch_bounds__(256) void selfattn_kernel(const float *__restrict__
     }
 }
 
+// One thread per (b, head, query, 4 consecutive d): merge the nsplit partial softmax states.
+__global__ __launch_bounds__(256) void combine_kernel(const float *__restrict__ part, float *__restrict__ out, int B,
+                                                      int H, int S, int nsplit, long long out_row_stride) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int d4 = (int)(gid & 15);
+    const long long row = gid >> 4;  // (b * H + head) * S + query
+    if (row >= (long long)B * H * S) return;
+    const size_t slice = (size_t)B * H * S * (kD + 2);
+    const float *p0 = part + (size_t)row * (kD + 2);
+    float m = -1e30f;
+    for (int s = 0; s < nsplit; ++s) m = fmaxf(m, p0[s * slice + kD]);
+    float l = 0.f, o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+        const float *p = p0 + s * slice;
+        const float w = __builtin_amdgcn_exp2f(p[kD] - m);
+        l += p[kD + 1] * w;
+        o0 += p[4 * d4] * w, o1 += p[4 * d4 + 1] * w, o2 += p[4 * d4 + 2] * w, o3 += p[4 * d4 + 3] * w;
+    }
+    const float inv = 1.0f / l;
+    const int qi = (int)(row % S), head = (int)((row / S) % H), b = (int)(row / ((long long)S * H));
+    float *orow = out + ((size_t)b * S + qi) * out_row_stride + head * kD + 4 * d4;
+    *reinterpret_cast<float4 *>(orow) = make_float4(o0 * inv, o1 * inv, o2 * inv, o3 * inv);
+}
+
+// Key-range split that best balances the (q-tile, head, batch) workgroups over the chip: a CU runs two workgroups
+// at a time (LDS / registers), so the kernel lasts ceil(blocks * s / CUs) slices of 1/s of the key sweep.
+static int choose_split(int B, int S, int H, int num_cus) {
+    const long long blocks = (long long)((S + kBM - 1) / kBM) * H * B;
+    const int ntiles = (S + kBN - 1) / kBN;
+    int best = 1;
+    double best_cost = (double)((blocks + num_cus - 1) / num_cus);
+    for (int s = 2; s <= 8; ++s) {
+        if (ntiles / s < 8) break;  // keep slices long enough to amortise the Q load and the combine pass
+        const double cost = (double)((blocks * s + num_cus - 1) / num_cus) / s + 0.02 * s;
+        if (cost < best_cost - 1e-9) best_cost = cost, best = s;
+    }
+    return best;
+}
+
 }  // namespace attn
 }  // namespace amav
 
 using namespace amav;
 
+static int attn_num_cus() {
+    static const int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+            v = 256;
+        return v;
+    }();
+    return n;
+}
+
+extern "C" size_t amav_selfattn_workspace_bytes(int B, int S, int H, int D) {
+    if (B <= 0 || S <= 0 || H <= 0 || D != attn::kD) return 0;
+    const int ns = attn::choose_split(B, S, H, attn_num_cus());
+    return ns > 1 ? (size_t)ns * B * H * S * (attn::kD + 2) * sizeof(float) : 256;
+}
+
 extern "C" int amav_selfattn_forward(int B, int S, int H, int D, const float *q, const float *k, const float *v,
                                      int64_t row_stride, float *out, int64_t out_row_stride, float scale,
-                                     void *stream) {
+                                     void *workspace, size_t workspace_bytes, void *stream_) {
     AMAV_REQUIRE(B > 0 && S > 0 && H > 0, "amav_selfattn_forward: bad sizes B=%d S=%d H=%d", B, S, H);
     AMAV_REQUIRE(D == attn::kD, "amav_selfattn_forward: head_dim %d (only %d is built)", D, attn::kD);
     AMAV_REQUIRE(q && k && v && out, "amav_selfattn_forward: NULL pointer");
@@ -175,9 +252,18 @@ extern "C" int amav_selfattn_forward(int B, int S, int H, int D, const float *q,
                    reinterpret_cast<uintptr_t>(out)) & 15) == 0,
                  "amav_selfattn_forward: q/k/v/out must be 16-byte aligned");
     AMAV_REQUIRE(H <= 65535 && B <= 65535, "amav_selfattn_forward: grid too large");
-    const dim3 grid((S + attn::kBM - 1) / attn::kBM, H, B);
-    attn::selfattn_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(q, k, v, out, S, row_stride,
-                                                                             out_row_stride,
-                                                                             scale * 1.4426950408889634f);
+    const int ns = attn::choose_split(B, S, H, attn_num_cus());
+    const size_t need = ns > 1 ? (size_t)ns * B * H * S * (attn::kD + 2) * sizeof(float) : 0;
+    if (ns > 1 && (workspace == nullptr || workspace_bytes < need))
+        return fail(AMAV_ERR_WORKSPACE, "amav_selfattn_forward: workspace %zu < required %zu", workspace_bytes, need);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const dim3 grid((unsigned)((S + attn::kBM - 1) / attn::kBM) * ns, H, B);
+    attn::selfattn_kernel<<<grid, 256, 0, stream>>>(q, k, v, out, S, row_stride, out_row_stride,
+                                                    scale * 1.4426950408889634f, ns, static_cast<float *>(workspace));
+    if (ns > 1) {
+        const long long threads = (long long)B * H * S * 16;
+        attn::combine_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, stream>>>(static_cast<const float *>(workspace),
+                                                                                    out, B, H, S, ns, out_row_stride);
+    }
     return check_launch("amav_selfattn_forward");
 }

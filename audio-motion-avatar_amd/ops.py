@@ -381,7 +381,11 @@ def selfattn(q, k, v, heads, scale=None):
     if k.shape != q.shape or v.shape != q.shape or not (q.stride(1) == k.stride(1) == v.stride(1)):
         raise AmavError("selfattn: q, k, v must share shape and row stride")
     out = torch.empty(B, S, HD, device=q.device)
+    nbytes = _lib.lib().amav_selfattn_workspace_bytes(B, S, heads, D)
+    if nbytes == 0:
+        raise AmavError(f"amav_selfattn_workspace_bytes rejected B={B} S={S} H={heads} D={D}")
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
     check(_lib.lib().amav_selfattn_forward(B, S, heads, D, q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(1),
                                            out.data_ptr(), HD, float(scale if scale is not None else D ** -0.5),
-                                           _stream()), "amav_selfattn_forward")
+                                           ws.data_ptr(), nbytes, _stream()), "amav_selfattn_forward")
     return out

@@ -199,11 +199,13 @@ int amav_triplane_sample_features(int num_frames, int num_points, int channels, 
  * Self-attention of the audio transformer (diffusers Attention -> F.scaled_dot_product_attention as reached from
  * src/models/transformers.py:329-336): softmax(Q K^T * scale) V, fp32 in/out, no mask, on MFMA
  * (v_mfma_f32_32x32x2_f32, exact fp32 products).  q,k,v,out: [B, S, H*D] with row stride `row_stride` floats
- * (so a fused QKV projection output can be passed without a copy); D must be 64.
+ * (so a fused QKV projection output can be passed without a copy); D must be 64.  The key sweep may be split over
+ * several workgroups for load balance; their partial softmax states live in the caller's workspace.
  */
+size_t amav_selfattn_workspace_bytes(int batch, int seq_len, int heads, int head_dim);
 int amav_selfattn_forward(int batch, int seq_len, int heads, int head_dim, const float *q_dev, const float *k_dev,
                           const float *v_dev, int64_t row_stride, float *out_dev, int64_t out_row_stride,
-                          float scale, void *stream);
+                          float scale, void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }
