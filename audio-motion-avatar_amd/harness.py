@@ -1,0 +1,105 @@
+"""Lightning-free caller of the hot path: the build's counterpart of `AudioDrivenTriplaneAvatarLightning`
+(src/models/lightning_model_wrapper.py:392-657) and of the `main2.py --mode demo` loop (src/main2.py:123-340).
+
+Only the inference I/O of the boundary is reproduced (SURVEY.md section 8b "caller harness"):
+
+  * `predict_step`  : (reference tokens, audio + cameras) -> `audio_rendered_images [B,T_out,H,W,3]`
+                      (lightning_model_wrapper.py:574-605,640).  The stage-1 encoder that turns reference IMAGES
+                      into tokens (`self.triplane_gaussian`, :592-597) is out of scope: the
+                      caller passes the tokens it produced.
+  * `rollout`       : the demo's window chaining -- every window of T_out frames is generated from the last two
+                      outputs of the previous one (main2.py:179-203: `triplanes, smplx_tokens = out[:, -2:]`).
+  * `rollout_sharded`: the multi-GPU form: each rank rolls and renders its own contiguous block of windows
+                      (segment-parallel, SURVEY section 8e option i) and the clip is reassembled by an all-gather of
+                      uint8 frames.
+  * `load_reference_checkpoint`: `checkpoint['state_dict']` with the `audio_triplane.` / `triplane_gaussian.renderer.`
+                      prefixes (main2.py:127-138, strict=False like the reference).
+
+Deterministic inference semantics: modules run in eval mode (the reference's demo leaves them in .train(),
+main2.py:140-141, which makes its own output non-reproducible).
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .config import ModelConfig
+from .dist import all_gather_frames, shard_range
+from .renderer import Renderer
+from .smplx_decoder import SMPLXDecoder
+from .triplane_audio_net import AudioTriplaneNet
+
+
+class AudioDrivenAvatar(nn.Module):
+    def __init__(self, cfg: ModelConfig = None):
+        super().__init__()
+        self.cfg = cfg or ModelConfig()
+        rcfg = self.cfg.renderer
+        self.smpl_decoder = SMPLXDecoder(rcfg)
+        # one Renderer shared by both stages, as in the reference (lightning_model_wrapper.py:405-406)
+        self.renderer = Renderer(rcfg, smpl_decoder=self.smpl_decoder)
+        self.audio_triplane = AudioTriplaneNet(self.cfg, renderer=self.renderer)
+        self.to(rcfg.device).eval()
+
+    # ---- checkpoint ----------------------------------------------------------------------------------------------
+    def load_reference_checkpoint(self, path_or_state, strict=False):
+        """Load the tensors of a reference checkpoint; returns (missing, unexpected) of the audio_triplane load.
+        Uses torch.load(weights_only=True): nothing from the file is executed."""
+        state = path_or_state
+        if isinstance(path_or_state, str):
+            state = torch.load(path_or_state, map_location="cpu", weights_only=True)
+        if "state_dict" in state:
+            state = state["state_dict"]
+        audio = {k[len("audio_triplane."):]: v for k, v in state.items() if k.startswith("audio_triplane.")}
+        # the renderer appears under both prefixes (it is one shared module); take whichever is present
+        rend = {k[len("triplane_gaussian.renderer."):]: v for k, v in state.items()
+                if k.startswith("triplane_gaussian.renderer.")}
+        drop = ("point_encoder.", "point_refiner.", "triplane_upsampler.", "smplx_model.")  # 8(f) rows / file buffers
+        audio = {k: v for k, v in audio.items() if not k.startswith(tuple("renderer." + d for d in drop))}
+        rend = {k: v for k, v in rend.items() if not k.startswith(drop)}
+        result = self.audio_triplane.load_state_dict(audio, strict=strict)
+        if rend:
+            self.renderer.load_state_dict(rend, strict=False)
+        return result
+
+    # ---- one window ----------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def predict_step(self, triplanes, smplx_tokens, audio_features, cam_params, ref_img_features=None):
+        """lightning_model_wrapper.py:599-605,640: returns audio_rendered_images [B,T_out,H,W,3]."""
+        return self.audio_triplane(audio_features, triplanes, ref_img_features, cam_params, smplx_tokens)[0]
+
+    # ---- chained windows (demo) ------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def rollout(self, triplanes, smplx_tokens, audio_features, cam_params, num_windows=None):
+        """main2.py:179-203.  audio_features [B, W*T_out(+), 768], cam_params [B, W*T_out, ...] -> dict with
+        images [B, W*T_out, H, W, 3] plus the final two token sets (to continue the clip later)."""
+        T = self.audio_triplane.T_output
+        W = audio_features.shape[1] // T if num_windows is None else num_windows
+        if W < 1 or audio_features.shape[1] < W * T or cam_params["intrinsic"].shape[1] < W * T:
+            raise ValueError(f"need {W * T} audio tokens and cameras for {W} windows of {T} frames")
+        images = []
+        for w in range(W):
+            sl = slice(w * T, (w + 1) * T)
+            cam = {k: v[:, sl] for k, v in cam_params.items()}
+            out = self.audio_triplane(audio_features[:, sl], triplanes, None, cam, smplx_tokens)
+            images.append(out[0])
+            triplanes, smplx_tokens = out[3][:, -2:], out[4][:, -2:]  # chain into the next window
+        return {"images": torch.cat(images, dim=1), "triplanes": triplanes, "smplx_tokens": smplx_tokens}
+
+    @torch.no_grad()
+    def rollout_sharded(self, triplanes, smplx_tokens, audio_features, cam_params, group=None):
+        """Every rank generates and renders a contiguous block of windows starting from the SAME reference tokens
+        (as training seeds every window from the encoder, lightning_model_wrapper.py:435-466), then the frames are
+        all-gathered as uint8 RGB.  Returns uint8 [world * frames_per_rank, H, W, 3] (batch item 0)."""
+        import torch.distributed as dist
+
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        T = self.audio_triplane.T_output
+        windows = audio_features.shape[1] // T
+        if windows % world:
+            raise ValueError(f"{windows} windows do not split evenly over {world} ranks")
+        w0, w1 = shard_range(windows, world, rank)
+        sl = slice(w0 * T, w1 * T)
+        cam = {k: v[:, sl] for k, v in cam_params.items()}
+        local = self.rollout(triplanes, smplx_tokens, audio_features[:, sl], cam)["images"]
+        rgba = torch.cat([local[0], torch.ones_like(local[0][..., :1])], dim=-1).contiguous()
+        return all_gather_frames(ops.frames_to_rgb8(rgba), group)

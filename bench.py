@@ -29,6 +29,22 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
+def pmc_traffic_bytes(kernel_substr):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC summary of this same command
+    (profiles/r01_bench_render_pmc_hbm.csv: separate FETCH_SIZE / WRITE_SIZE passes, values in KB; see
+    profiles/README.md for the gfx950 caveats).  None when the summary is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_bench_render_pmc_hbm.csv")
+    try:
+        with open(path) as fh:
+            for line in fh.read().splitlines()[1:]:
+                cols = line.rsplit(",", 3)
+                if kernel_substr in cols[0]:
+                    return (float(cols[2]) + float(cols[3])) * 1024.0
+    except (OSError, ValueError, IndexError):
+        pass
+    return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -350,7 +366,8 @@ def main():
                    "instances_per_step": int(total), "stream_pipelined_frame_groups": len(workspaces),
                    "exchange": "all-gather of uint8 RGB frames over RCCL" if dist is not None else "none"},
         "roofline": {"bound": "hbm", "kernel": "render_kernel (tile blend)", "achieved": achieved,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": pmc_traffic_bytes("render_kernel") if (F, N, H) == (250, 10000, 512) else None,
                      "avg_launch_ms": blend_avg_ms, "algorithmic_bytes_per_launch": blend_bytes},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

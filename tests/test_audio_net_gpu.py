@@ -82,3 +82,42 @@ def test_forward_returns_the_reference_five_tuple():
     with torch.no_grad():
         nxt = net(audio[:, 3:], out_tri[:, -2:], None, cam, out_smpl[:, -2:])
     assert nxt[0].shape == images.shape
+
+
+def test_harness_rollout_chains_windows_like_the_demo_loop():
+    """harness.AudioDrivenAvatar.rollout == calling the net window by window and feeding back out[:, -2:]
+    (main2.py:179-203); load_reference_checkpoint reads the reference's state_dict prefixes."""
+    from audio_motion_avatar_amd.harness import AudioDrivenAvatar
+    from audio_motion_avatar_amd.synthetic import init_random_heads, make_render_inputs
+
+    cfg = small_cfg()
+    model = AudioDrivenAvatar(cfg)
+    randomize(model.audio_triplane.transformer, 5)
+    init_random_heads(model.renderer)
+    model = model.cuda()
+    # a "reference checkpoint": same tensors under the reference's key prefixes, plus keys that must be ignored
+    state = {"audio_triplane." + k: v.detach().cpu().clone() for k, v in model.audio_triplane.state_dict().items()}
+    state.update({"triplane_gaussian.renderer." + k: v.detach().cpu().clone()
+                  for k, v in model.renderer.state_dict().items()})
+    state["triplane_gaussian.renderer.point_refiner.0.weight"] = torch.zeros(4, 4)
+    state["triplane_gaussian.sapiens_encoder.x"] = torch.zeros(1)
+    other = AudioDrivenAvatar(cfg)
+    result = other.load_reference_checkpoint({"state_dict": state})
+    assert not result.missing_keys
+    B, T, W = 1, 3, 2
+    _, _, cam = make_render_inputs(T * W, cfg.renderer, seed=8, batch=B)
+    g = torch.Generator().manual_seed(3)
+    audio = torch.randn(B, T * W, 48, generator=g).cuda()
+    tri = torch.randn(B, 2, 32, 192, generator=g).cuda()
+    smpl = (torch.randn(B, 2, 32, 10, generator=g) * 0.2).cuda()
+    out = model.rollout(tri, smpl, audio, cam)
+    assert out["images"].shape == (B, T * W, 64, 64, 3)
+    same = other.rollout(tri, smpl, audio, cam)["images"]
+    assert torch.equal(out["images"], same)          # the loaded copy reproduces the original bit for bit
+    cam0 = {k: v[:, :T] for k, v in cam.items()}
+    cam1 = {k: v[:, T:] for k, v in cam.items()}
+    with torch.no_grad():
+        first = model.audio_triplane(audio[:, :T], tri, None, cam0, smpl)
+        second = model.audio_triplane(audio[:, T:], first[3][:, -2:], None, cam1, first[4][:, -2:])
+    assert torch.equal(out["images"][:, :T], first[0]) and torch.equal(out["images"][:, T:], second[0])
+    assert torch.equal(model.predict_step(tri, smpl, audio[:, :T], cam0), first[0])

@@ -126,3 +126,28 @@ def test_activations_and_clamp_match_render_one():
     assert ((rgba[0, :, :, :3] - ref[0, 0]).abs() * stable[..., None]).max() <= TOL
     assert ((rgba[0, :, :, 3] - ref_alpha[0, 0]).abs() * stable).max() <= TOL
     assert (rgba[0, :, :, :3] - ref[0, 0]).abs().max() <= FLIP_TOL
+
+
+def test_stress_config_one_frame():
+    """BASELINE configs[4] geometry: 1024x1024, 50k Gaussians (one frame keeps the oracle in seconds)."""
+    scene = random_scene(77, 50000, 1024, 1024, 1, spread=0.45, log_scale=-5.2, scale_jitter=0.6)
+    compare(scene, run_hip(scene))
+
+
+def test_ted_image_size_non_square_partial_tiles():
+    """The reference's own frame size is 1296 x 2304 (ted_speech.yaml:14): 81 x 144 tiles; here a quarter of it,
+    with a width and height that are not multiples of 16."""
+    scene = random_scene(78, 4000, 325, 577, 1, spread=0.5, log_scale=-4.0)
+    compare(scene, run_hip(scene))
+
+
+def test_full_ted_frame_runs():
+    from audio_motion_avatar_amd import ops
+
+    scene = random_scene(79, 3000, 1296, 2304, 1, spread=0.6, log_scale=-4.2, focal=2304.0)
+    out = run_hip(scene)
+    ref = oracle_frames(scene, np.float32)[0]
+    rgba = out["rgba"].cpu().numpy()[0]
+    stable = ref["unstable"] == 0
+    assert (np.abs(np.moveaxis(rgba[..., :3], -1, 0) - ref["color"]) * stable).max() <= TOL
+    assert np.array_equal(out["radii"][0].cpu().numpy(), ref["radii"])
