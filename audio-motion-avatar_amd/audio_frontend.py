@@ -1,0 +1,70 @@
+"""Audio front-end: waveform -> one Wav2Vec2 feature vector per video frame.
+
+Mirror of `GaussianAudioDataset._extract_audio_features` (src/datasets/dataset_speech_vid.py:37-116), which the
+reference runs on the CPU at dataset construction: mono mix, crop to the video length at its hard-coded 30 fps
+(:54-62), clips of `clip_length` frames through `Wav2Vec2Model` (:68-89; the processor's per-clip zero-mean /
+unit-variance normalisation included), mean-pool `time_steps // frames` hidden states per frame (:94-105), pad or
+trim to the frame count (:107-113).  On-wire format `[T, 768]` fp32 -- what `AudioTriplaneNet.forward` consumes.
+
+Here the model runs on the MI355X through PyTorch-ROCm library kernels (MIOpen convolutions, rocBLAS GEMMs): this is
+plumbing around the hot path, not one of its hand-written kernels.  The checkpoint `facebook/wav2vec2-base-960h` is
+not available offline; `build_wav2vec2()` constructs the same architecture with random weights (or loads a local
+directory when one is given).  Resampling needs torchaudio (absent): the waveform must already be at `sample_rate`.
+"""
+import torch
+
+
+def build_wav2vec2(model_path=None, device="cuda", seed=0):
+    from transformers import Wav2Vec2Config, Wav2Vec2Model
+
+    if model_path:
+        model = Wav2Vec2Model.from_pretrained(model_path, local_files_only=True)
+    else:
+        torch.manual_seed(seed)
+        model = Wav2Vec2Model(Wav2Vec2Config())  # base-960h architecture: 7 conv layers, 12 x 768 transformer
+    return model.to(device).eval()
+
+
+def _normalize(clip):
+    """Wav2Vec2FeatureExtractor(do_normalize=True): (x - mean) / sqrt(var + 1e-7) per clip."""
+    return (clip - clip.mean()) / torch.sqrt(clip.var(unbiased=False) + 1e-7)
+
+
+@torch.no_grad()
+def extract_audio_features(waveform, sr, frames_count, model, clip_length=8, sample_rate=16000,
+                           estimated_frame_rate=30):
+    """waveform [channels, samples] (or [samples]) at `sr` Hz -> features [frames_count, hidden] on the model's device."""
+    if sr != sample_rate:
+        raise NotImplementedError(f"resampling {sr} -> {sample_rate} Hz needs torchaudio (absent here); "
+                                  "resample before calling")
+    device = next(model.parameters()).device
+    waveform = waveform.to(device=device, dtype=torch.float32)
+    if waveform.dim() == 1:
+        waveform = waveform[None]
+    if waveform.shape[0] > 1:
+        waveform = waveform.mean(dim=0, keepdim=True)                       # :44-45
+    audio_duration = waveform.shape[1] / sample_rate
+    video_duration = frames_count / estimated_frame_rate                     # :54-55 (30 fps is hard-coded)
+    if audio_duration > video_duration:                                      # :57-62
+        waveform = waveform[:, : int(video_duration * sample_rate)]
+        audio_duration = video_duration
+    frame_duration = audio_duration / frames_count
+    features = []
+    for start_idx in range(0, frames_count, clip_length):                    # :68-105
+        end_idx = min(start_idx + clip_length, frames_count)
+        start_sample = int(start_idx * frame_duration * sample_rate)
+        end_sample = min(int(end_idx * frame_duration * sample_rate), waveform.shape[1])
+        if start_sample >= end_sample:
+            start_sample = max(0, waveform.shape[1] - int((end_idx - start_idx) * frame_duration * sample_rate))
+            end_sample = waveform.shape[1]
+        clip = _normalize(waveform[0, start_sample:end_sample])
+        hidden = model(clip[None]).last_hidden_state                        # [1, steps, hidden]
+        steps = hidden.shape[1]
+        frames_in_clip = end_idx - start_idx
+        per = max(1, steps // frames_in_clip)
+        for i in range(frames_in_clip):
+            a, b = min(i * per, steps - 1), min((i + 1) * per, steps)
+            features.append(hidden[0, a:b].mean(dim=0) if a < b else hidden[0, a])
+    if len(features) < frames_count:                                         # :107-113
+        features.extend([features[-1]] * (frames_count - len(features)))
+    return torch.stack(features[:frames_count])

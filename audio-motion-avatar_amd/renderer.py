@@ -12,7 +12,8 @@ Changed on purpose (MI355X-first):
     are views into it;
   * the vertex subset is drawn once (seeded) instead of on every forward (renderer.py:287), and no stage prints or
     synchronises (renderer.py:76-82);
-  * `upsample_triplane=True` and the PTv3 point refiner are SURVEY.md section 8(f) next-rows: requesting them raises.
+  * the PTv3 point refiner is a SURVEY.md section 8(f) next-row: requesting it raises; `upsample_triplane=True` runs
+    the TriplaneUpsampler through library convolutions (torch / MIOpen), then the same fused decode.
 There is no CPU path: every tensor must be on the HIP device.
 """
 import numpy as np
@@ -37,9 +38,6 @@ class Renderer(nn.Module):
     def __init__(self, cfg=None, smpl_decoder=None):
         super().__init__()
         self.cfg = cfg
-        if getattr(cfg, "upsample_triplane", False):
-            raise NotImplementedError("upsample_triplane=True (TriplaneUpsampler, renderer.py:377-417) is a SURVEY "
-                                      "8(f) next-row and is not built; set upsample_triplane=False")
         if not getattr(cfg, "no_point_refiner", True):
             raise NotImplementedError("the PTv3 point refiner (renderer.py:34-47,143-151) is a SURVEY 8(f) next-row; "
                                       "set no_point_refiner=True (an untrained refiner outputs zero offsets anyway)")
@@ -47,6 +45,8 @@ class Renderer(nn.Module):
         self.num_verts = SUBDEVIDE_VERTS[self.cfg.subdivide_steps]
         self.init_smplx_subdivider(subdivide_steps=self.cfg.subdivide_steps)
         self.smpl_decoder = smpl_decoder if cfg.predict_smplx_params else None
+        if getattr(cfg, "upsample_triplane", False):
+            self.triplane_upsampler = TriplaneUpsampler(cfg)
 
         C = cfg.triplane_feature_dim
         self.gaussian_decoder = nn.Module()
@@ -122,10 +122,17 @@ class Renderer(nn.Module):
                                                            gd.xyz_layer.weight.device))
         return self._packed[1]
 
+    def _plane_resolution(self, triplane_tokens):
+        """Resolution of the planes inside a token slab [F,C,3 R^2] (R grows 2^num_upsample_blocks when upsampled)."""
+        r = int(round((triplane_tokens.shape[-1] // 3) ** 0.5))
+        if 3 * r * r != triplane_tokens.shape[-1]:
+            raise AmavError(f"token length {triplane_tokens.shape[-1]} is not 3 * R^2")
+        return r
+
     def decode_gaussians(self, triplane_tokens, points, transl):
         """Fused renderer.py:136-181: tokens [F,C,3R^2], points [F,N,3], transl [F,3] -> packed [F,N,16]."""
         w_plane, w_point = self._head_weights()
-        proj = ops.triplane_project(triplane_tokens, w_plane, self.cfg.triplane_resolution)
+        proj = ops.triplane_project(triplane_tokens, w_plane, self._plane_resolution(triplane_tokens))
         return ops.triplane_sample_decode(proj, points, transl, self.cfg.radius, w_point)
 
     def gaussians_from_tokens(self, triplane_tokens, smpl_params, out=None, side_work=None):
@@ -147,7 +154,7 @@ class Renderer(nn.Module):
         side.wait_stream(cur)
         side_result = None
         with torch.cuda.stream(side):
-            proj = ops.triplane_project(triplane_tokens, w_plane, self.cfg.triplane_resolution)
+            proj = ops.triplane_project(triplane_tokens, w_plane, self._plane_resolution(triplane_tokens))
             if side_work is not None:
                 side_result = side_work()
         vertices = self._posed_vertices(smpl_params)
@@ -236,6 +243,8 @@ class Renderer(nn.Module):
             raise AmavError("Renderer.forward needs smpl_tokens (the reference dereferences it too, renderer.py:84)")
         B, T = smpl_tokens.shape[:2]
         tokens = triplane_features.reshape(B * T, triplane_features.shape[2], triplane_features.shape[3]).float()
+        if getattr(self.cfg, "upsample_triplane", False):  # renderer.py:94-99 (library convolutions, 8(f) row 2)
+            tokens = self.triplane_upsampler.forward_tokens(tokens, self.cfg.triplane_resolution)
 
         pred_smpl_params = None
         if self.smpl_decoder is not None:
@@ -257,6 +266,66 @@ class Renderer(nn.Module):
         if self.cfg.predict_smplx_params:
             return rendered_images, gaussians, pred_smpl_params
         return rendered_images, gaussians
+
+
+class ResBlock(nn.Module):
+    """renderer.py:348-362 (module layout kept so `triplane_upsampler.*` checkpoint keys load)."""
+
+    def __init__(self, in_channels, out_channels, norm_layer=nn.BatchNorm2d):
+        super().__init__()
+        self.block = nn.Sequential(norm_layer(in_channels), nn.ReLU(inplace=True),
+                                   nn.Conv2d(in_channels, out_channels, 3, padding=1), norm_layer(out_channels),
+                                   nn.ReLU(inplace=True), nn.Conv2d(out_channels, out_channels, 3, padding=1))
+        self.skip = nn.Conv2d(in_channels, out_channels, 1) if in_channels != out_channels else nn.Identity()
+
+    def forward(self, x):
+        return self.skip(x) + self.block(x)
+
+
+class UpsampleBlock(nn.Module):
+    """renderer.py:364-375: nearest x2 -> conv3x3 -> ReLU -> ResBlock."""
+
+    def __init__(self, in_channels, out_channels, scale_factor=2):
+        super().__init__()
+        self.upsample = nn.Sequential(nn.Upsample(scale_factor=scale_factor, mode="nearest"),
+                                      nn.Conv2d(in_channels, out_channels, 3, padding=1), nn.ReLU(inplace=True),
+                                      ResBlock(out_channels, out_channels))
+
+    def forward(self, x):
+        return self.upsample(x)
+
+
+class TriplaneUpsampler(nn.Module):
+    """renderer.py:377-417: `num_upsample_blocks` x (UpsampleBlock + nearest-upsampled skip) on the three planes.
+    SURVEY section 8(f) row 2: library convolutions (MIOpen through torch), not a hand-written kernel; eval-mode
+    BatchNorm.  At the reference defaults (4 blocks, C=256, 32^2 -> 512^2) this is ~3.7 TFLOP and 805 MB per frame."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        c = cfg.triplane_feature_dim
+        n = cfg.num_upsample_blocks
+        self.upsample_blocks = nn.ModuleList([UpsampleBlock(c, c, 2) for _ in range(n)])
+        self.skip_connections = nn.ModuleList([
+            nn.Sequential(nn.Conv2d(c, c, 1) if i == 0 else nn.Identity(), nn.Upsample(scale_factor=2, mode="nearest"))
+            for i in range(n)])
+
+    def forward(self, triplanes):
+        """[B,3,C,H,W] -> [B,3,C,2^n H,2^n W]"""
+        B, P, C, H, W = triplanes.shape
+        cur = triplanes.reshape(B * P, C, H, W)
+        skip = cur
+        for block, skip_conn in zip(self.upsample_blocks, self.skip_connections):
+            skip = skip_conn(skip)
+            cur = block(cur) + skip
+        return cur.reshape(B, P, C, cur.shape[-2], cur.shape[-1])
+
+    def forward_tokens(self, tokens, resolution):
+        """Token slab [F,C,3 R^2] -> [F,C,3 (2^n R)^2] (what the fused decode consumes)."""
+        F, C, _ = tokens.shape
+        planes = tokens.reshape(F, C, 3, resolution, resolution).permute(0, 2, 1, 3, 4)
+        up = self.forward(planes)
+        return up.permute(0, 2, 1, 3, 4).reshape(F, C, -1)
 
 
 ### Gaussian Splatting Renderer ###

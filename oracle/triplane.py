@@ -60,3 +60,27 @@ def decode_gaussians(params, triplane_features, points, transl, radius):
     feats = sample_from_triplane(triplane_features, points, radius)
     decoder_input = torch.cat([points, feats], dim=-1)
     return construct_gaussians(gaussian_heads(params, decoder_input), points, transl)
+
+
+def triplane_upsampler(params, triplanes, num_blocks, prefix="triplane_upsampler.", eps=1e-5):
+    """renderer.py:377-417 restated with torch functionals (eval-mode BatchNorm: running statistics).
+    triplanes [B,3,C,H,W] -> [B,3,C,2^n H,2^n W]."""
+    B, P, C, H, W = triplanes.shape
+    cur = triplanes.reshape(B * P, C, H, W)
+    skip = cur
+    conv = lambda x, name, pad: F.conv2d(x, params[prefix + name + ".weight"], params[prefix + name + ".bias"],
+                                         padding=pad)
+    bn = lambda x, name: F.batch_norm(x, params[prefix + name + ".running_mean"], params[prefix + name + ".running_var"],
+                                      params[prefix + name + ".weight"], params[prefix + name + ".bias"], False, 0.0, eps)
+    up = lambda x: F.interpolate(x, scale_factor=2, mode="nearest")
+    for i in range(num_blocks):
+        b = f"upsample_blocks.{i}.upsample."
+        x = F.relu(conv(up(cur), b + "1", 1))
+        r = conv(F.relu(bn(x, b + "3.block.0")), b + "3.block.2", 1)
+        r = conv(F.relu(bn(r, b + "3.block.3")), b + "3.block.5", 1)
+        x = x + r  # ResBlock with identity skip (in == out channels)
+        if i == 0:
+            skip = conv(skip, "skip_connections.0.0", 0)
+        skip = up(skip)
+        cur = x + skip
+    return cur.reshape(B, P, C, cur.shape[-2], cur.shape[-1])

@@ -110,3 +110,36 @@ def test_renderer_forward_drop_in_signature():
     mv = render_multi_view(one, cam["intrinsic"][:1], cam["extrinsic"][:1], cfg)
     assert mv.shape == (1, T, H, W, 3)
     assert torch.equal(mv[0, 0], images[0, 0])
+
+
+def test_triplane_upsampler_path_matches_oracle():
+    """cfg.upsample_triplane=True (renderer.py:94-99): library convolutions on the GPU, then the
+    fused decode at the upsampled resolution, against the CPU restatement."""
+    from audio_motion_avatar_amd.config import RendererConfig
+    from audio_motion_avatar_amd.renderer import Renderer
+    from audio_motion_avatar_amd.synthetic import init_random_heads, make_render_inputs
+    from oracle import lbs as o_lbs, subdivide as o_sub, triplane as o_tri
+
+    torch.manual_seed(0)
+    cfg = RendererConfig(image_size=(64, 64), subdivide_steps=0, triplane_feature_dim=16, triplane_resolution=4,
+                         predict_smplx_params=False, upsample_triplane=True, num_upsample_blocks=2)
+    r = init_random_heads(Renderer(cfg).eval(), std=0.05)
+    for m in r.triplane_upsampler.modules():   # non-trivial running statistics
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.2)
+            m.running_var.uniform_(0.5, 1.5)
+    F_ = 2
+    tokens, smpl, cam = make_render_inputs(F_, cfg, seed=2)
+    with torch.no_grad():
+        images, gaussians = r(tokens, cam, torch.zeros(1, F_, 1, 1, device="cuda"), smpl)
+    params = {"triplane_upsampler." + k: v.detach().cpu() for k, v in r.triplane_upsampler.state_dict().items()}
+    params.update({"gaussian_decoder." + k: v.detach().cpu() for k, v in r.gaussian_decoder.state_dict().items()})
+    planes = o_tri.triplane_upsampler(params, o_tri.tokens_to_planes(tokens.cpu(), 4), 2)
+    assert planes.shape == (F_, 3, 16, 16, 16)
+    levels = o_sub.subdivision_levels(r.smplx_model.faces, r.smplx_model.num_verts, 1)
+    sp = {k: v.cpu() for k, v in smpl.items()}
+    pts = o_lbs.get_smpl_vertices(r.smplx_model.oracle_arrays(torch.float32), sp, densify=(levels, r.subset_index))
+    g = o_tri.decode_gaussians(params, planes, pts, sp["transl"].reshape(-1, 3), cfg.radius)
+    for k in ("xyz", "scale", "rot", "opacity", "color"):
+        assert (gaussians[k].cpu() - g[k]).abs().max() <= 1e-4, k
+    assert images.shape == (1, F_, 64, 64, 3)
