@@ -255,7 +255,12 @@ class BodyModel(torch.nn.Module):
         nc = dirs.shape[2]
         blend = np.concatenate([dirs.reshape(V * 3, nc).T, arrays["posedirs"].astype(np.float64)], axis=0)
         kb = blend.shape[0]
-        blend = np.ascontiguousarray(blend.reshape(kb, V, 3).transpose(0, 2, 1))  # [KB, 3, V] component planes
+        # tile-major component planes [ceil(V/32), KB, 3, 32] (zero padded): a 32-vertex tile's rows are one contiguous
+        # slab, which is what the skinning kernels stream (csrc/lbs.hip)
+        vt = (V + 31) // 32
+        planes = np.zeros((kb, 3, vt * 32), np.float64)
+        planes[:, :, :V] = blend.reshape(kb, V, 3).transpose(0, 2, 1)
+        blend = np.ascontiguousarray(planes.reshape(kb, 3, vt, 32).transpose(2, 0, 1, 3))
         Jreg = arrays["J_regressor"].astype(np.float64)
         j_template = Jreg @ arrays["v_template"].astype(np.float64)                  # [J,3]
         j_dirs = np.einsum("jv,vcl->jcl", Jreg, dirs).reshape(J * 3, nc)            # [J*3, NC]

@@ -130,8 +130,8 @@ __global__ __launch_bounds__(64) void joint_chain_kernel(Tables t, int F, int Fp
     }
 }
 
-// grid: ceil(V/256) * (Fpad/FT) blocks.  featT rows are [k][Fpad]; A is [Fpad][J][12]; blend is [KB][3][V] (component
-// planes, so a wave's loads are three fully coalesced 256-byte rows per k).
+// grid: ceil(V/256) * (Fpad/FT) blocks.  featT rows are [k][Fpad]; A is [Fpad][J][12]; blend is tile-major
+// [ceil(V/32)][KB][3][32] (a wave's loads are two coalesced 128-byte rows per component and k).
 // Block order: the frame groups of one vertex chunk are adjacent AND land on one XCD (blocks are dealt round-robin
 // over 8 XCDs), so each 1.5 MB chunk of the 64 MB blend table is fetched from HBM once and then re-read from that
 // XCD's L2 by the other frame groups (placement only affects speed).
@@ -161,11 +161,10 @@ __global__ __launch_bounds__(256) void skin_kernel(Tables t, int F, int Fpad, in
 #pragma unroll
         for (int m = 0; m < FT; ++m) acc[m][0] = x, acc[m][1] = y, acc[m][2] = z;
     }
-    const float *bl = t.blend + v;
-    const size_t plane = (size_t)t.V, row = 3 * (size_t)t.V;
+    const float *bl = t.blend + (size_t)(v >> 5) * t.KB * 96 + (v & 31);  // tile-major table: [V/32][KB][3][32]
 #pragma unroll 4
     for (int k = 0; k < t.KB; ++k) {
-        const float b0 = bl[k * row], b1 = bl[k * row + plane], b2 = bl[k * row + 2 * plane];
+        const float b0 = bl[k * 96], b1 = bl[k * 96 + 32], b2 = bl[k * 96 + 64];
         const float *fk = feat_lds + k * FT;  // same address in every lane: LDS broadcast
 #pragma unroll
         for (int m = 0; m < FT; ++m) {
@@ -211,6 +210,138 @@ __global__ __launch_bounds__(256) void skin_kernel(Tables t, int F, int Fpad, in
     }
 }
 
+// MFMA form of the same stage for F > 16: the blend product [F, KB] x [KB, 3V] is a GEMM, so it runs on
+// v_mfma_f32_32x32x2_f32 (exact fp32 products and sums; twice the FMA rate of the vector pipe, and one operand word
+// per lane per 4096 flops instead of an LDS broadcast per FMA, which is what bounds skin_kernel).
+//   block  = 4 waves = 128 frames x one 32-vertex tile; wave = 32 frames x 32 vertices x 3 components = three 32x32
+//            accumulators whose column (lane & 31) is the vertex and whose rows (8g + 4*(lane >> 5) + r in register
+//            4g + r) are frames: the skinning epilogue finds x, y, z of a (frame, vertex) pair in one lane and a
+//            store instruction writes 384 contiguous bytes per frame.
+//   table  : tile-major, so a block streams ONE contiguous 194 KB slab, in 12 KB chunks of 32 rows that the block
+//            stages through LDS (double buffered, one barrier per chunk): each table byte leaves HBM once per
+//            128 frames instead of once per wave that happens to miss L2.
+//   feats  : featT[k][frame] rows straight from L2 (0.5 MB, hot), one chunk ahead in registers; rows past KB are zero
+//            (host pads featT), so the last chunk needs no special case.
+// The frame groups of a vertex tile are adjacent in block order and share an XCD (as in skin_kernel).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kMfmaWaves = 4;                    // frame tiles (of 32) per block
+constexpr int kMfmaKC = 32;                      // table rows per staged chunk
+constexpr int kMfmaChunk4 = kMfmaKC * 96 / 4;    // float4 per chunk (768)
+constexpr int kMfmaKPad = 2 * kMfmaKC;           // zero rows appended to featT on this path
+
+__global__ __launch_bounds__(64 * kMfmaWaves, 3) void skin_mfma_kernel(Tables t, int F, int Fpad, int ntiles,
+                                                                    const float *__restrict__ featT,
+                                                                    const float *__restrict__ A,
+                                                                    float *__restrict__ out) {
+    __shared__ float4 Bs[2][kMfmaChunk4];
+    const int ngroups = (Fpad / 32 + kMfmaWaves - 1) / kMfmaWaves;
+    const int xcd = blockIdx.x & 7, bj = blockIdx.x >> 3;
+    const int tile = (bj / ngroups) * 8 + xcd, fg = bj % ngroups;
+    if (tile >= ntiles) return;  // block-uniform
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ftile = fg * kMfmaWaves + wave;
+    const bool active = ftile * 32 < Fpad;  // a wave without frames still helps staging and joins the barriers
+    const int f0 = active ? ftile * 32 : 0;
+    const int c = lane & 31, hh = lane >> 5;
+    const int v = tile * 32 + c;
+
+    f32x16 X, Y, Z;
+    {
+        const int vl = min(v, t.V - 1);
+        const float x = t.v_template[vl * 3], y = t.v_template[vl * 3 + 1], z = t.v_template[vl * 3 + 2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) X[r] = x, Y[r] = y, Z[r] = z;
+    }
+    const float4 *bt4 = reinterpret_cast<const float4 *>(t.blend + (size_t)tile * t.KB * 96);
+    const int total4 = t.KB * 24;  // float4 in this tile's slab
+    const int nchunks = (t.KB + kMfmaKC - 1) / kMfmaKC;
+    const unsigned lane_a = (unsigned)(hh * Fpad + f0 + c);
+    float4 breg[3];
+    float a_cur[kMfmaKC / 2], a_nxt[kMfmaKC / 2];
+    auto gload = [&](int ch) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int idx = ch * kMfmaChunk4 + (int)threadIdx.x + 256 * i;
+            breg[i] = idx < total4 ? bt4[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto aload = [&](float (&a)[kMfmaKC / 2], int ch) {
+        const float *pa = featT + (size_t)(ch * kMfmaKC) * Fpad;
+#pragma unroll
+        for (int s = 0; s < kMfmaKC / 2; ++s) a[s] = pa[(size_t)(2 * s) * Fpad + lane_a];
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) Bs[buf][threadIdx.x + 256 * i] = breg[i];
+    };
+    gload(0);
+    aload(a_cur, 0);
+    stage(0);
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int buf = ch & 1;
+        // always issued (the last iteration re-reads its own chunk and discards it): a conditional prefetch would
+        // make the compiler wait for the loads it has just issued
+        const int nxt = min(ch + 1, nchunks - 1);
+        gload(nxt);
+        aload(a_nxt, nxt);
+        __builtin_amdgcn_sched_barrier(0);  // the next chunk's loads stay ahead of this chunk's MFMAs
+        if (active) {
+            const float *bs = reinterpret_cast<const float *>(Bs[buf]) + hh * 96 + c;
+            float q0 = bs[0], q1 = bs[32], q2 = bs[64];
+#pragma unroll
+            for (int s = 0; s < kMfmaKC / 2; ++s) {
+                const float p0 = q0, p1 = q1, p2 = q2;
+                if (s + 1 < kMfmaKC / 2) q0 = bs[(s + 1) * 192], q1 = bs[(s + 1) * 192 + 32], q2 = bs[(s + 1) * 192 + 64];
+                X = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[s], p0, X, 0, 0, 0);
+                Y = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[s], p1, Y, 0, 0, 0);
+                Z = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[s], p2, Z, 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        stage(buf ^ 1);  // last read in iteration ch - 1, before that iteration's barrier
+#pragma unroll
+        for (int s = 0; s < kMfmaKC / 2; ++s) a_cur[s] = a_nxt[s];
+        __syncthreads();
+    }
+    if (!active) return;
+    if (v >= t.V) return;
+
+    int jidx[8];
+    float jw[8];
+    const int kw = t.KW;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        jidx[k] = k < kw ? t.skin_idx[(size_t)v * kw + k] : 0;
+        jw[k] = k < kw ? t.skin_w[(size_t)v * kw + k] : 0.0f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int f = f0 + 8 * (r >> 2) + 4 * hh + (r & 3);
+        if (f >= F) continue;
+        float Tm[12];
+#pragma unroll
+        for (int e = 0; e < 12; ++e) Tm[e] = 0.0f;
+        const float *Af = A + (size_t)f * t.J * 12;
+        auto add = [&](int ji, float w) {
+            const float4 *a4 = reinterpret_cast<const float4 *>(Af + ji * 12);
+            const float4 r0 = a4[0], r1 = a4[1], r2 = a4[2];
+            Tm[0] += w * r0.x, Tm[1] += w * r0.y, Tm[2] += w * r0.z, Tm[3] += w * r0.w;
+            Tm[4] += w * r1.x, Tm[5] += w * r1.y, Tm[6] += w * r1.z, Tm[7] += w * r1.w;
+            Tm[8] += w * r2.x, Tm[9] += w * r2.y, Tm[10] += w * r2.z, Tm[11] += w * r2.w;
+        };
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (k < kw) add(jidx[k], jw[k]);
+        for (int k = 8; k < kw; ++k) add(t.skin_idx[(size_t)v * kw + k], t.skin_w[(size_t)v * kw + k]);
+        const float x = X[r], y = Y[r], z = Z[r];
+        float *o = out + ((size_t)f * t.V + v) * 3;
+        o[0] = Tm[0] * x + Tm[1] * y + Tm[2] * z + Tm[3];
+        o[1] = Tm[4] * x + Tm[5] * y + Tm[6] * z + Tm[7];
+        o[2] = Tm[8] * x + Tm[9] * y + Tm[10] * z + Tm[11];
+    }
+}
+
 __global__ __launch_bounds__(256) void gather_kernel(int V, int N, const float *__restrict__ verts,
                                                      const int4 *__restrict__ idx, float *__restrict__ out) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -227,11 +358,14 @@ __global__ __launch_bounds__(256) void gather_kernel(int V, int N, const float *
     }
 }
 
-static int frame_tile(int F) {
-    static const int forced = getenv("AMAV_LBS_FT") ? atoi(getenv("AMAV_LBS_FT")) : 0;  // tuning aid: 4, 8, 16 or 32
+// Frames per thread of skin_kernel, or 0: the MFMA kernel (F > 16; frames padded to its 32-row tiles).
+static int frame_tile(int F, int /*KB*/) {
+    static const int forced = getenv("AMAV_LBS_FT") ? atoi(getenv("AMAV_LBS_FT")) : -1;  // tuning aid: 0, 4, 8, 16, 32
     if (forced == 4 || forced == 8 || forced == 16 || forced == 32) return forced;
-    return F <= 8 ? 4 : 16;
+    if (forced == 0) return 0;
+    return F <= 8 ? 4 : (F <= 16 ? 16 : 0);
 }
+static int frame_pad(int F, int FT) { return FT ? (F + FT - 1) / FT * FT : (F + 31) / 32 * 32; }
 
 }  // namespace lbs
 }  // namespace amav
@@ -247,15 +381,16 @@ static int validate_tables(const amav_body_tables *t, const char *who) {
     AMAV_REQUIRE(t->skin_k > 0 && t->skin_k <= t->num_joints, "%s: bad skin_k %d", who, t->skin_k);
     AMAV_REQUIRE(t->v_template && t->blend && t->j_template && t->j_dirs && t->parents && t->skin_idx && t->skin_w,
                  "%s: NULL table", who);
+    AMAV_REQUIRE((reinterpret_cast<uintptr_t>(t->blend) & 15) == 0, "%s: blend table not 16-byte aligned", who);
     return AMAV_OK;
 }
 
 static size_t lbs_ws(int F, const amav_body_tables *t, float **featT, float **A, void *ws) {
-    const int FT = frame_tile(F);
-    const int Fpad = (F + FT - 1) / FT * FT;
     const int KB = t->num_coeffs + (t->num_joints - 1) * 9;
+    const int FT = frame_tile(F, KB);
+    const int Fpad = frame_pad(F, FT);
     Carver c(ws);
-    float *ft = c.take<float>((size_t)KB * Fpad);
+    float *ft = c.take<float>((size_t)(KB + (FT ? 0 : kMfmaKPad)) * Fpad);
     float *a = c.take<float>((size_t)Fpad * t->num_joints * 12);
     if (featT) *featT = ft;
     if (A) *A = a;
@@ -282,14 +417,22 @@ extern "C" int amav_lbs_forward(int F, const amav_body_tables *tb, const float *
     t.KB = t.NC + (t.J - 1) * 9;
     t.v_template = tb->v_template, t.blend = tb->blend, t.j_template = tb->j_template, t.j_dirs = tb->j_dirs;
     t.parents = tb->parents, t.skin_idx = tb->skin_idx, t.skin_w = tb->skin_w;
-    const int FT = frame_tile(F);
-    const int Fpad = (F + FT - 1) / FT * FT;
+    const int FT = frame_tile(F, t.KB);
+    const int Fpad = frame_pad(F, FT);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    // padded frame columns of featT must be finite (they feed FMAs whose results are discarded)
-    if (Fpad != F && hipMemsetAsync(featT, 0, (size_t)t.KB * Fpad * sizeof(float), stream) != hipSuccess)
+    // padded frame columns of featT must be finite (they feed FMAs whose results are discarded), and the MFMA path
+    // reads kMfmaKPad zero rows past the table
+    const size_t feat_rows = (size_t)t.KB + (FT ? 0 : kMfmaKPad);
+    if ((Fpad != F || FT == 0) && hipMemsetAsync(featT, 0, feat_rows * Fpad * sizeof(float), stream) != hipSuccess)
         return fail(AMAV_ERR_LAUNCH, "amav_lbs_forward: hipMemsetAsync failed");
     float *A_dst = out_A ? out_A : A;
     joint_chain_kernel<<<F, 64, 0, stream>>>(t, F, Fpad, full_pose, coeffs, featT, A_dst);
+    if (FT == 0) {
+        const int ntiles = (t.V + 31) / 32, ngroups = (Fpad / 32 + kMfmaWaves - 1) / kMfmaWaves;
+        const unsigned mgrid = (unsigned)(((ntiles + 7) / 8) * 8 * ngroups);
+        skin_mfma_kernel<<<mgrid, 64 * kMfmaWaves, 0, stream>>>(t, F, Fpad, ntiles, featT, A_dst, out_vertices);
+        return check_launch("amav_lbs_forward");
+    }
     const int nchunks = (t.V + 255) / 256;
     const unsigned grid = (unsigned)(((nchunks + 7) / 8) * 8 * (Fpad / FT));
     const size_t lds = (size_t)FT * t.KB * sizeof(float);

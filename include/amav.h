@@ -128,8 +128,9 @@ int amav_frames_to_rgb8(int64_t num_pixels, const float *rgba_dev, uint8_t *out_
  * Replaces smplx.SMPLX.forward -> smplx.lbs.lbs as called at src/models/renderer.py:261-274 (no transl;
  * use_pca=False).  Model constants are immutable device tables prepared once by the host mirror
  * (audio-motion-avatar_amd/body_model.py) from the SMPL-X arrays:
- *   v_template [V,3]; blend [(n_coeff + (J-1)*9), 3, V] (x / y / z planes per row): rows 0..n_coeff-1 = shape +
- *   expression directions, then posedirs; j_template [J,3] = J_regressor v_template; j_dirs [J*3, n_coeff] = J_regressor applied to
+ *   v_template [V,3]; blend [ceil(V/32), KB, 3, 32] with KB = n_coeff + (J-1)*9: for every tile of 32 vertices (the
+ *   last one zero padded) the KB blend rows as x / y / z planes, rows 0..n_coeff-1 = shape + expression directions,
+ *   then posedirs; 16-byte aligned; j_template [J,3] = J_regressor v_template; j_dirs [J*3, n_coeff] = J_regressor applied to
  *   the shape directions; parents [J]; skin_idx / skin_w [V, skin_k]: the non-zero LBS weights of each vertex in
  *   ascending joint order, padded with weight 0.
  */

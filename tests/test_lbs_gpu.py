@@ -26,7 +26,7 @@ def oracle_verts(pose, coeffs, dtype):
     return lbs.lbs(coeffs.to(dtype), pose.to(dtype) + m["pose_mean"], m)
 
 
-@pytest.mark.parametrize("F", [1, 4, 6, 19])
+@pytest.mark.parametrize("F", [1, 4, 6, 16, 19, 33, 150])  # <= 16: FMA kernels; above: the MFMA kernel (32-frame tiles)
 def test_lbs_random_poses(F):
     from audio_motion_avatar_amd import ops
 
@@ -37,6 +37,28 @@ def test_lbs_random_poses(F):
     assert (verts.cpu() - v32).abs().max() <= TOL
     assert (verts.cpu().double() - v64).abs().max() <= TOL
     assert (A.cpu().reshape(F, -1, 3, 4) - A32[:, :, :3, :]).abs().max() <= TOL
+
+
+def test_mfma_and_fma_kernels_agree(monkeypatch):
+    """The two skinning kernels compute the same sums in different orders: far inside the 1e-5 bar of each other."""
+    import subprocess
+    import sys
+
+    code = ("import torch, sys; sys.path.insert(0, 'tests'); from helpers import random_pose;"
+            "from audio_motion_avatar_amd import ops; from audio_motion_avatar_amd.body_model import BodyModel;"
+            "b = BodyModel.synthetic_model(seed=42, device='cuda'); p, c = random_pose(7, 70, scale=0.3);"
+            "v = ops.lbs_forward(b.device_tables(), p.cuda(), c.cuda()); torch.save(v.cpu(), sys.argv[1])")
+    import os
+    import tempfile
+
+    outs = []
+    for ft in ("0", "16"):  # AMAV_LBS_FT is read once per process
+        with tempfile.NamedTemporaryFile(suffix=".pt") as f:
+            env = dict(os.environ, AMAV_LBS_FT=ft)
+            subprocess.run([sys.executable, "-c", code, f.name], check=True, env=env,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            outs.append(torch.load(f.name, weights_only=True))
+    assert (outs[0] - outs[1]).abs().max() <= 2e-6
 
 
 def test_identity_pose_returns_shaped_template():

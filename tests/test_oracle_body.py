@@ -115,7 +115,13 @@ def test_synthetic_body_is_smplx_shaped():
 
     b = body()
     assert b.num_verts == 10475 and b.num_joints == 55
-    assert b._blend.shape == (20 + 54 * 9, 3, 10475)
+    # blend table handed to the C ABI: tile-major [ceil(V/32), KB, 3, 32], zero padded, = shape/expression dirs + posedirs
+    assert b._blend.shape == (328, 20 + 54 * 9, 3, 32)
+    planes = b._blend.permute(1, 2, 0, 3).reshape(506, 3, 328 * 32)
+    assert (planes[..., 10475:] == 0).all()
+    a = b.oracle_arrays(torch.float32)
+    assert torch.equal(planes[:10, :, :10475], a["shapedirs"].permute(2, 1, 0))
+    assert torch.equal(planes[20:, :, :10475], a["posedirs"].reshape(486, 10475, 3).permute(0, 2, 1))
     assert np.array_equal(b.parents, SMPLX_PARENTS) and b.parents[0] == -1 and (b.parents[1:] < np.arange(1, 55)).all()
     w = b.lbs_weights
     assert torch.allclose(w.sum(1), torch.ones(10475), atol=1e-6) and (w >= 0).all()
