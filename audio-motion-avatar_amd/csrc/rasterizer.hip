@@ -486,6 +486,109 @@ __device__ __forceinline__ void rank_sort(unsigned long long *keys, unsigned *or
     wave_sync();
 }
 
+// Bucket sort of 64 < n <= 64 * KPL unique keys by one wave, O(n / 64) per lane for well spread depths.  The depth
+// word of a key is mapped monotonically onto 512 buckets between the tile's nearest and farthest Gaussian, the keys
+// are counted (packed 16-bit LDS counters), the counts are scanned, every key is placed into its bucket's slice, and
+// ties inside a bucket are ordered by comparing the full 64-bit keys of the slice, so the result is the exact
+// (depth, id) order whatever the depths are.  Returns false (keys stored to LDS, nothing sorted) when a bucket holds
+// more than kBucketMax keys: clustered depths are left to the comparison sorts.
+constexpr int kBuckets512 = 512;
+constexpr int kBucketMax = 16;
+
+template <int KPL>
+__device__ __forceinline__ bool bucket_sort(const unsigned long long *__restrict__ gkeys, unsigned long long *slice,
+                                            unsigned *cnt, unsigned *order, int n, int lane) {
+    unsigned long long k[KPL];
+    unsigned dmin = 0xffffffffu, dmax = 0u;
+#pragma unroll
+    for (int m = 0; m < KPL; ++m) {
+        const bool in = lane + 64 * m < n;
+        k[m] = in ? gkeys[lane + 64 * m] : ~0ull;
+        const unsigned d = (unsigned)(k[m] >> 32);
+        if (in) dmin = min(dmin, d), dmax = max(dmax, d);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        dmin = min(dmin, (unsigned)__shfl_xor((int)dmin, o, 64));
+        dmax = max(dmax, (unsigned)__shfl_xor((int)dmax, o, 64));
+    }
+    const float scale = dmax > dmin ? (float)(kBuckets512 - 1) / (float)(dmax - dmin) : 0.0f;
+    int b[KPL];
+#pragma unroll
+    for (int m = 0; m < KPL; ++m)  // monotone in the depth word: conversion, product and truncation all are
+        b[m] = min(kBuckets512 - 1, (int)((float)((unsigned)(k[m] >> 32) - dmin) * scale));
+    // counters: 256 words of two 16-bit counts (+ one word past the end for the scan's total)
+    reinterpret_cast<uint4 *>(cnt)[lane] = make_uint4(0u, 0u, 0u, 0u);
+    wave_sync();
+    unsigned pos[KPL];
+#pragma unroll
+    for (int m = 0; m < KPL; ++m) {
+        pos[m] = 0;
+        if (lane + 64 * m < n) {
+            const int sh = 16 * (b[m] & 1);
+            pos[m] = (atomicAdd(&cnt[b[m] >> 1], 1u << sh) >> sh) & 0xffffu;  // arrival index inside the bucket
+        }
+    }
+    wave_sync();
+    // exclusive scan of the 512 counts: lane owns buckets 8*lane .. 8*lane + 7
+    const uint4 w = reinterpret_cast<uint4 *>(cnt)[lane];
+    unsigned c[8] = {w.x & 0xffffu, w.x >> 16, w.y & 0xffffu, w.y >> 16, w.z & 0xffffu, w.z >> 16, w.w & 0xffffu, w.w >> 16};
+    unsigned tot = 0, big = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const unsigned ci = c[i];
+        big = max(big, ci);
+        c[i] = tot;
+        tot += ci;
+    }
+    unsigned incl = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned up = (unsigned)__shfl_up((int)incl, o, 64);
+        if (lane >= o) incl += up;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) big = max(big, (unsigned)__shfl_xor((int)big, o, 64));
+    if (big > (unsigned)kBucketMax) {  // wave-uniform
+        wave_sync();
+#pragma unroll
+        for (int m = 0; m < KPL; ++m)
+            if (lane + 64 * m < n) slice[lane + 64 * m] = k[m];
+        wave_sync();
+        return false;
+    }
+    const unsigned base = incl - tot;
+    reinterpret_cast<uint4 *>(cnt)[lane] =
+        make_uint4((base + c[0]) | ((base + c[1]) << 16), (base + c[2]) | ((base + c[3]) << 16),
+                   (base + c[4]) | ((base + c[5]) << 16), (base + c[6]) | ((base + c[7]) << 16));
+    if (lane == 0) cnt[kBuckets512 / 2] = (unsigned)n;  // start of the bucket past the last one
+    wave_sync();
+    unsigned st[KPL], sz[KPL];
+#pragma unroll
+    for (int m = 0; m < KPL; ++m) {
+        st[m] = (cnt[b[m] >> 1] >> (16 * (b[m] & 1))) & 0xffffu;
+        const int nb = b[m] + 1;
+        sz[m] = ((cnt[nb >> 1] >> (16 * (nb & 1))) & 0xffffu) - st[m];
+        if (lane + 64 * m < n) slice[st[m] + pos[m]] = k[m];
+    }
+    wave_sync();
+#pragma unroll
+    for (int m = 0; m < KPL; ++m) {
+        unsigned r = pos[m];
+        if (lane + 64 * m < n && sz[m] > 1u) {  // order the bucket by the full key
+            r = 0;
+            for (unsigned j = 0; j < sz[m]; ++j) r += (unsigned)(slice[st[m] + j] < k[m]);
+        }
+        pos[m] = st[m] + r;
+    }
+    wave_sync();  // the ids overwrite the slice: every lane has finished reading it
+#pragma unroll
+    for (int m = 0; m < KPL; ++m)
+        if (lane + 64 * m < n) order[pos[m]] = (unsigned)k[m];
+    wave_sync();
+    return true;
+}
+
 // Bitonic sort of n (wave-uniform, n <= kSortCap) unique keys in LDS by one wave: O(n log^2 n / 64) comparators
 // against the rank sort's O(n^2 / 64) compares; it wins above 256 keys (measured: 31 us against 52 us per tile for
 // n in [256, 512), 16 against 13 for [128, 256)).  Normalised network (every comparator orders lo < hi ascending), so
@@ -609,18 +712,33 @@ __device__ __forceinline__ void render_tile(const Params &p, WaveLds &L, int ite
         unsigned *order_l = reinterpret_cast<unsigned *>(L.keys);
         const bool local = n <= kSortCap;
         if (local) {
-            for (int k = lane; k < n; k += 64) L.keys[k] = keys[k];
-            wave_sync();
-            if (n <= 64)
-                rank_sort<1>(L.keys, order_l, n, lane);
-            else if (n <= 128)
-                rank_sort<2>(L.keys, order_l, n, lane);
+            unsigned *cnt = reinterpret_cast<unsigned *>(L.stage);  // the staging buffers are idle while sorting
+            bool done = false;
+            if (n <= 64) {
+                for (int k = lane; k < n; k += 64) L.keys[k] = keys[k];
+                wave_sync();
+            } else if (n <= 128)
+                done = bucket_sort<2>(keys, L.keys, cnt, order_l, n, lane);
             else if (n <= 192)
-                rank_sort<3>(L.keys, order_l, n, lane);
+                done = bucket_sort<3>(keys, L.keys, cnt, order_l, n, lane);
             else if (n <= 256)
-                rank_sort<4>(L.keys, order_l, n, lane);
+                done = bucket_sort<4>(keys, L.keys, cnt, order_l, n, lane);
+            else if (n <= 384)
+                done = bucket_sort<6>(keys, L.keys, cnt, order_l, n, lane);
             else
-                wave_bitonic_sort(L.keys, order_l, n, lane);
+                done = bucket_sort<8>(keys, L.keys, cnt, order_l, n, lane);
+            if (!done) {  // short list, or depths too clustered for buckets: comparison sorts on the keys in LDS
+                if (n <= 64)
+                    rank_sort<1>(L.keys, order_l, n, lane);
+                else if (n <= 128)
+                    rank_sort<2>(L.keys, order_l, n, lane);
+                else if (n <= 192)
+                    rank_sort<3>(L.keys, order_l, n, lane);
+                else if (n <= 256)
+                    rank_sort<4>(L.keys, order_l, n, lane);
+                else
+                    wave_bitonic_sort(L.keys, order_l, n, lane);
+            }
         }
         AMAV_STAMP(2);
 
