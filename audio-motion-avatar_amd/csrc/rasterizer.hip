@@ -419,10 +419,20 @@ __device__ __forceinline__ void bitonic_sort(unsigned long long *a, int n, int t
     }
 }
 
+// Lists longer than kSortCap, one 256-thread block per list.  Up to kBigLdsCap keys: the block form of the blend
+// kernel's bucket sort (2048 depth buckets, exact: ties inside a bucket are ordered by the full key), about ten
+// barriers instead of the bitonic network's sixty-six; clustered depths (a bucket above kBigBucketMax keys) and longer
+// lists take the bitonic network.
+constexpr int kBigBuckets = 2048;
+constexpr int kBigBucketMax = 32;
+
 __global__ __launch_bounds__(256) void sort_big_kernel(Params p) {
     __shared__ unsigned long long big_lds[kBigLdsCap];
+    __shared__ __align__(16) unsigned cnt[kBigBuckets / 2 + 4];
+    __shared__ unsigned part[12];
     if (p.buf.status->overflow) return;
     const int count = p.buf.status->big_count;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int w = blockIdx.x; w < count; w += gridDim.x) {
         const int gt = p.buf.big_list[w];
         const int f = gt / p.T, t = gt % p.T;
@@ -430,6 +440,100 @@ __global__ __launch_bounds__(256) void sort_big_kernel(Params p) {
         const int beg = off[t], n = off[t + 1] - beg;
         unsigned long long *keys = p.buf.keys + (size_t)f * p.cap_per_frame + beg;
         unsigned *sorted = p.buf.sorted + (size_t)f * p.cap_per_frame + beg;
+        bool done = false;
+        if (n <= kBigLdsCap) {
+            constexpr int KPT = kBigLdsCap / 256;  // 8 keys and 8 buckets per thread
+            unsigned long long k[KPT];
+            unsigned dmin = 0xffffffffu, dmax = 0u;
+#pragma unroll
+            for (int m = 0; m < KPT; ++m) {
+                const bool in = tid + 256 * m < n;
+                k[m] = in ? keys[tid + 256 * m] : ~0ull;
+                const unsigned d = (unsigned)(k[m] >> 32);
+                if (in) dmin = min(dmin, d), dmax = max(dmax, d);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                dmin = min(dmin, (unsigned)__shfl_xor((int)dmin, o, 64));
+                dmax = max(dmax, (unsigned)__shfl_xor((int)dmax, o, 64));
+            }
+            if (lane == 0) part[wave] = dmin, part[4 + wave] = dmax;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) cnt[tid + 256 * i] = 0u;
+            __syncthreads();
+            dmin = min(min(part[0], part[1]), min(part[2], part[3]));
+            dmax = max(max(part[4], part[5]), max(part[6], part[7]));
+            const float scale = dmax > dmin ? (float)(kBigBuckets - 1) / (float)(dmax - dmin) : 0.0f;
+            int b[KPT];
+            unsigned pos[KPT];
+#pragma unroll
+            for (int m = 0; m < KPT; ++m) {
+                b[m] = min(kBigBuckets - 1, (int)((float)((unsigned)(k[m] >> 32) - dmin) * scale));
+                pos[m] = 0;
+                if (tid + 256 * m < n) {
+                    const int sh = 16 * (b[m] & 1);
+                    pos[m] = (atomicAdd(&cnt[b[m] >> 1], 1u << sh) >> sh) & 0xffffu;
+                }
+            }
+            __syncthreads();
+            // exclusive scan of the 2048 counts: thread owns buckets 8*tid .. 8*tid + 7
+            const uint4 wv = reinterpret_cast<uint4 *>(cnt)[tid];
+            unsigned c[8] = {wv.x & 0xffffu, wv.x >> 16, wv.y & 0xffffu, wv.y >> 16,
+                             wv.z & 0xffffu, wv.z >> 16, wv.w & 0xffffu, wv.w >> 16};
+            unsigned tot = 0, big = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const unsigned ci = c[i];
+                big = max(big, ci);
+                c[i] = tot;
+                tot += ci;
+            }
+            unsigned incl = tot;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned up = (unsigned)__shfl_up((int)incl, o, 64);
+                if (lane >= o) incl += up;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) big = max(big, (unsigned)__shfl_xor((int)big, o, 64));
+            __syncthreads();  // everyone has read part[] and its counters
+            if (lane == 63) part[wave] = incl;
+            if (lane == 0) part[4 + wave] = big;
+            __syncthreads();
+            big = max(max(part[4], part[5]), max(part[6], part[7]));
+            if (big <= (unsigned)kBigBucketMax) {  // block-uniform
+                unsigned base = incl - tot;
+                for (int i = 0; i < wave; ++i) base += part[i];
+                reinterpret_cast<uint4 *>(cnt)[tid] =
+                    make_uint4((base + c[0]) | ((base + c[1]) << 16), (base + c[2]) | ((base + c[3]) << 16),
+                               (base + c[4]) | ((base + c[5]) << 16), (base + c[6]) | ((base + c[7]) << 16));
+                if (tid == 0) cnt[kBigBuckets / 2] = (unsigned)n;
+                __syncthreads();
+                unsigned st[KPT], sz[KPT];
+#pragma unroll
+                for (int m = 0; m < KPT; ++m) {
+                    st[m] = (cnt[b[m] >> 1] >> (16 * (b[m] & 1))) & 0xffffu;
+                    const int nb = b[m] + 1;
+                    sz[m] = ((cnt[nb >> 1] >> (16 * (nb & 1))) & 0xffffu) - st[m];
+                    if (tid + 256 * m < n) big_lds[st[m] + pos[m]] = k[m];
+                }
+                __syncthreads();
+#pragma unroll
+                for (int m = 0; m < KPT; ++m) {
+                    if (tid + 256 * m < n) {
+                        unsigned r = pos[m];
+                        if (sz[m] > 1u) {
+                            r = 0;
+                            for (unsigned j = 0; j < sz[m]; ++j) r += (unsigned)(big_lds[st[m] + j] < k[m]);
+                        }
+                        sorted[st[m] + r] = (unsigned)k[m];
+                    }
+                }
+                done = true;
+            }
+            __syncthreads();  // LDS is reused by the next list (or by the fallback below)
+        }
+        if (done) continue;
         if (n <= kBigLdsCap) {
             for (int k = threadIdx.x; k < n; k += blockDim.x) big_lds[k] = keys[k];
             __syncthreads();
