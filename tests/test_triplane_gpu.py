@@ -22,7 +22,8 @@ def make_case(seed, F, N, C, R, wstd=0.02):
     return tokens, points, transl, params
 
 
-@pytest.mark.parametrize("F,N,C,R", [(1, 256, 16, 8), (3, 1000, 256, 32), (2, 777, 64, 6), (1, 64, 32, 5)])
+@pytest.mark.parametrize("F,N,C,R", [(1, 256, 16, 8), (3, 1000, 256, 32), (2, 777, 64, 6), (1, 64, 32, 5),
+                                     (1, 50000, 512, 128)])  # last: BASELINE configs[4] (stress) decode shape
 def test_fused_decode_matches_grid_sample_plus_heads(F, N, C, R):
     from audio_motion_avatar_amd import ops
     from oracle import triplane as orc
@@ -42,7 +43,10 @@ def test_fused_decode_matches_grid_sample_plus_heads(F, N, C, R):
                color=rec[..., 12:15])
     for k, v in got.items():
         assert (v - ref[k]).abs().max() <= 2e-5, k
-        assert (v.double() - ref64[k]).abs().max() <= 2e-5, k
+        # against fp64: 2e-5, or (long sums: C = 512 is 1539 terms, and normalising a short quaternion amplifies their
+        # rounding) no worse than four times the fp32 reference's own distance from fp64
+        own = (ref[k].double() - ref64[k]).abs().max().item()
+        assert (v.double() - ref64[k]).abs().max() <= max(2e-5, 4 * own), k
     assert torch.count_nonzero(rec[..., 11]) == 0 and torch.count_nonzero(rec[..., 15]) == 0
 
 
