@@ -97,7 +97,6 @@ struct Params {
     long long cap_per_frame;
     int qcap;  // entries per work queue
     unsigned long long *stamps;  // diagnostic: [F*T][6] s_memtime stamps per tile wave, or NULL
-    int debug_flags;  // AMAV_RASTER_DEBUG (timing ablations only: 1 = no sort, 2 = no blend, 4 = no stores)
     Buffers buf;
 };
 
@@ -116,25 +115,34 @@ __device__ __forceinline__ void wave_sync() {
 // One Gaussian of frame f.  Contraction is off and the operation order is the oracle's (oracle/raster_ref.c): +, *,
 // /, sqrt are correctly rounded on both sides, so depth keys, radii and tile rectangles -- the decisions that move
 // whole Gaussians between tiles or swap their blend order -- come out bit-identical to the CPU restatement.
+struct GaussRec {
+    float4 r0, r1, r2, r3;  // xyz,opacity | rotation | scale,- | colour,-
+};
+
+// kPacked: the five attributes are views of one packed [.., 16] record (triplane.hip layout): four 16-byte loads
 template <bool kPacked>
-__device__ __forceinline__ uint4 preprocess_one(const Params &p, int f, int i, const float *vm, const float *pm,
-                                                float tanx, float tany, int &upstream_tiles) {
-#pragma clang fp contract(off)
-    const size_t gi = (size_t)f * p.N + i;
-    uint4 rd = make_uint4(0u, 0u, 0u, 0u);
-    // kPacked: the five attributes are views of one packed [.., 16] record (triplane.hip layout): four 16-byte loads
-    float4 rec0, rec1, rec2, rec3;
+__device__ __forceinline__ GaussRec load_gaussian(const Params &p, int f, int i) {
+    GaussRec g;
     if (kPacked) {
         const float4 *rec = reinterpret_cast<const float4 *>(at(p.means3d, f, i));
-        rec0 = rec[0], rec1 = rec[1], rec2 = rec[2], rec3 = rec[3];
+        g.r0 = rec[0], g.r1 = rec[1], g.r2 = rec[2], g.r3 = rec[3];
     } else {
         const float *m_ = at(p.means3d, f, i), *q_ = at(p.rotations, f, i), *s_ = at(p.scales, f, i);
         const float *c_ = at(p.colors, f, i);
-        rec0 = make_float4(m_[0], m_[1], m_[2], at(p.opacities, f, i)[0]);
-        rec1 = make_float4(q_[0], q_[1], q_[2], q_[3]);
-        rec2 = make_float4(s_[0], s_[1], s_[2], 0.f);
-        rec3 = make_float4(c_[0], c_[1], c_[2], 0.f);
+        g.r0 = make_float4(m_[0], m_[1], m_[2], at(p.opacities, f, i)[0]);
+        g.r1 = make_float4(q_[0], q_[1], q_[2], q_[3]);
+        g.r2 = make_float4(s_[0], s_[1], s_[2], 0.f);
+        g.r3 = make_float4(c_[0], c_[1], c_[2], 0.f);
     }
+    return g;
+}
+
+__device__ __forceinline__ uint4 preprocess_one(const Params &p, int f, int i, const GaussRec &rec, const float *vm,
+                                                const float *pm, float tanx, float tany, int &upstream_tiles) {
+#pragma clang fp contract(off)
+    const size_t gi = (size_t)f * p.N + i;
+    uint4 rd = make_uint4(0u, 0u, 0u, 0u);
+    const float4 rec0 = rec.r0, rec1 = rec.r1, rec2 = rec.r2, rec3 = rec.r3;
     const float px3 = rec0.x, py3 = rec0.y, pz3 = rec0.z;
     const float vx = vm[0] * px3 + vm[4] * py3 + vm[8] * pz3 + vm[12];
     const float vy = vm[1] * px3 + vm[5] * py3 + vm[9] * pz3 + vm[13];
@@ -291,9 +299,13 @@ __global__ __launch_bounds__(1024) void bin_kernel(Params p) {
     const float tanx = p.tanfov[2 * f], tany = p.tanfov[2 * f + 1];
     // phase 1: preprocess, count instances per tile (LDS atomics)
     int upstream = 0;
+    // the next Gaussian's record is in flight while this one goes through the (long, dependent) projection maths
+    GaussRec cur = load_gaussian<kPacked>(p, f, min((int)threadIdx.x, p.N - 1));
     for (int i = threadIdx.x; i < p.N; i += blockDim.x) {
+        const GaussRec nxt = load_gaussian<kPacked>(p, f, min(i + (int)blockDim.x, p.N - 1));
         int up = 0;
-        const uint4 rd = preprocess_one<kPacked>(p, f, i, vm, pm, tanx, tany, up);
+        const uint4 rd = preprocess_one(p, f, i, cur, vm, pm, tanx, tany, up);
+        cur = nxt;
         upstream += up;
         const size_t gi = (size_t)f * p.N + i;
         p.buf.rectd[gi] = rd;
@@ -371,8 +383,11 @@ __global__ __launch_bounds__(1024) void bin_kernel(Params p) {
 
     // phase 3: scatter (depth, index) keys into the tile lists (order inside a list is fixed later by the sort)
     unsigned long long *keys = p.buf.keys + (size_t)f * p.cap_per_frame;
+    const uint4 *rect = p.buf.rectd + (size_t)f * p.N;
+    uint4 rd_next = rect[min((int)threadIdx.x, p.N - 1)];
     for (int i = threadIdx.x; i < p.N; i += blockDim.x) {
-        const uint4 rd = p.buf.rectd[(size_t)f * p.N + i];
+        const uint4 rd = rd_next;
+        rd_next = rect[min(i + (int)blockDim.x, p.N - 1)];
         if (rd.w == 0u) continue;
         const int rx0 = rd.x & 0xffff, ry0 = rd.x >> 16, rx1 = rd.y & 0xffff, ry1 = rd.y >> 16;
         const unsigned long long key = ((unsigned long long)rd.z << 32) | (unsigned)i;
@@ -1027,8 +1042,6 @@ extern "C" int amav_rasterize_forward(const amav_raster_args *a, void *stream_) 
     p.out_rgba = a->out_rgba, p.out_inv_depth = a->out_inv_depth, p.out_radii = a->out_radii;
     p.cap_per_frame = cap_per_frame;
     p.qcap = (int)queue_capacity(F, T);
-    static const int debug_flags = getenv("AMAV_RASTER_DEBUG") ? atoi(getenv("AMAV_RASTER_DEBUG")) : 0;
-    p.debug_flags = debug_flags;
     p.stamps = static_cast<unsigned long long *>(a->debug_stamps);
 
     hipStream_t stream = static_cast<hipStream_t>(stream_);
