@@ -42,6 +42,7 @@ class RendererConfig:
     # deterministic-inference additions (SURVEY.md "Hard parts"): the reference re-draws the vertex subset with
     # torch.randperm on every forward (renderer.py:287); here it is drawn once from this seed.
     subset_seed: int = 42
+    subset_order: str = "random"      # "spatial": the same subset, stored along a Z-order curve of the rest pose
     body_seed: int = 42               # seed of the synthetic body used when smplx_model_path is absent
     pipeline_chunks: int = 1          # >1: frame groups on separate HIP streams (measured slower on MI355X: 1.53 -> 1.79 ms)
 

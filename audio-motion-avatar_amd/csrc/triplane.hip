@@ -116,6 +116,11 @@ __device__ __forceinline__ Taps make_taps(float gx, float gy, int R) {
 //   q0 = (xyz_offset, opacity), q1 = rotation, q2 = (scaling, pad), q3 = (shs, pad)
 // kIndexed: the point is gathered from the posed vertices through the baked subdivision table (lbs.hip gather_kernel
 // fused in: 1/2 (1/2 (v[a0]+v[b0]) + 1/2 (v[a1]+v[b1])), the same operation order, so the same bits).
+template <int K>
+__device__ __forceinline__ float quad_bcast(float v) {  // value of lane K of this lane's quad
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), K * 0x55, 0xf, 0xf, true));
+}
+
 template <bool kIndexed>
 __global__ __launch_bounds__(256) void sample_decode_kernel(int F, int N, int R, int V,
                                                             const float *__restrict__ proj,
@@ -135,12 +140,15 @@ __global__ __launch_bounds__(256) void sample_decode_kernel(int F, int N, int R,
     if (n >= N) return;
     float p0, p1, p2;
     if (kIndexed) {
+        // the four lanes of a point fetch one base vertex each and trade them inside the quad (DPP), instead of
+        // every lane gathering all four
         const int4 id = idx4[n];
-        const float *vf = points + (size_t)f * V * 3;
-        const float *a0 = vf + id.x * 3, *b0 = vf + id.y * 3, *a1 = vf + id.z * 3, *b1 = vf + id.w * 3;
-        p0 = ((a0[0] + b0[0]) * 0.5f + (a1[0] + b1[0]) * 0.5f) * 0.5f;
-        p1 = ((a0[1] + b0[1]) * 0.5f + (a1[1] + b1[1]) * 0.5f) * 0.5f;
-        p2 = ((a0[2] + b0[2]) * 0.5f + (a1[2] + b1[2]) * 0.5f) * 0.5f;
+        const int mine = q == 0 ? id.x : (q == 1 ? id.y : (q == 2 ? id.z : id.w));
+        const float *vp = points + ((size_t)f * V + mine) * 3;
+        const float v0 = vp[0], v1 = vp[1], v2 = vp[2];
+        p0 = ((quad_bcast<0>(v0) + quad_bcast<1>(v0)) * 0.5f + (quad_bcast<2>(v0) + quad_bcast<3>(v0)) * 0.5f) * 0.5f;
+        p1 = ((quad_bcast<0>(v1) + quad_bcast<1>(v1)) * 0.5f + (quad_bcast<2>(v1) + quad_bcast<3>(v1)) * 0.5f) * 0.5f;
+        p2 = ((quad_bcast<0>(v2) + quad_bcast<1>(v2)) * 0.5f + (quad_bcast<2>(v2) + quad_bcast<3>(v2)) * 0.5f) * 0.5f;
     } else {
         const float *pp = points + ((size_t)f * N + n) * 3;
         p0 = pp[0], p1 = pp[1], p2 = pp[2];
@@ -150,6 +158,10 @@ __global__ __launch_bounds__(256) void sample_decode_kernel(int F, int N, int R,
     const float u2 = fminf(fmaxf(p2 / radius, -1.0f), 1.0f);
     const int RR = R * R;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    // branch-free taps: an out-of-range texel (zero padding) is read at a clamped address with weight 0, so the twelve
+    // 16-byte loads are issued back to back and their latencies overlap
+    float4 tv[12];
+    float tw[12];
 #pragma unroll
     for (int plane = 0; plane < 3; ++plane) {
         // plane 0 <- (x, y), plane 1 <- (x, z), plane 2 <- (y, z); grid x indexes W, grid y indexes H
@@ -162,12 +174,17 @@ __global__ __launch_bounds__(256) void sample_decode_kernel(int F, int N, int R,
 #pragma unroll
             for (int dx = 0; dx < 2; ++dx) {
                 const int ix = t.ix0 + dx, iy = t.iy0 + dy;
-                if (ix >= 0 && ix < R && iy >= 0 && iy < R) {
-                    const float w = (dx ? t.wx1 : t.wx0) * (dy ? t.wy1 : t.wy0);
-                    const float4 v = pl[(size_t)(iy * R + ix) * 4];
-                    acc.x += w * v.x, acc.y += w * v.y, acc.z += w * v.z, acc.w += w * v.w;
-                }
+                const bool in = ix >= 0 && ix < R && iy >= 0 && iy < R;
+                const int cx = min(max(ix, 0), R - 1), cy = min(max(iy, 0), R - 1);
+                tw[plane * 4 + dy * 2 + dx] = in ? (dx ? t.wx1 : t.wx0) * (dy ? t.wy1 : t.wy0) : 0.0f;
+                tv[plane * 4 + dy * 2 + dx] = pl[(size_t)(cy * R + cx) * 4];
             }
+    }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {  // same order as before: plane, then dy, then dx
+        const float w = tw[k];
+        const float4 v = tv[k];
+        acc.x += w * v.x, acc.y += w * v.y, acc.z += w * v.z, acc.w += w * v.w;
     }
     // + W_xyz p + bias  (wpoint [16][4]: 3 xyz weights, bias)
     const float4 *wp = reinterpret_cast<const float4 *>(wpoint) + q * 4;

@@ -29,6 +29,22 @@ SCALE_BIAS = ops.SCALE_BIAS
 OPACITY_BIAS = ops.OPACITY_BIAS
 
 
+def _morton_order(v_template, gather_idx):
+    """Order of the sampled points along a Z-order curve of their rest-pose positions.  The reference draws the
+    subset in a fresh random order on every forward (renderer.py:287), so any fixed order of the same set is as
+    faithful; a spatial one keeps neighbouring points (same triplane texels, same image tiles) in neighbouring lanes."""
+    vt = v_template.double()
+    a0, b0, a1, b1 = (gather_idx[:, k].long() for k in range(4))
+    pos = ((vt[a0] + vt[b0]) * 0.5 + (vt[a1] + vt[b1]) * 0.5) * 0.5
+    lo, hi = pos.min(0).values, pos.max(0).values
+    q = ((pos - lo) / (hi - lo).clamp_min(1e-12) * 1023.0).long().clamp(0, 1023)
+    code = torch.zeros(pos.shape[0], dtype=torch.long)
+    for bit in range(10):
+        for axis in range(3):
+            code |= ((q[:, axis] >> bit) & 1) << (3 * bit + axis)
+    return torch.argsort(code, stable=True)
+
+
 def inverse_sigmoid(x):
     """src/utils/math_utils.py:7-11."""
     return torch.log(x / (1 - x)) if isinstance(x, torch.Tensor) else float(np.log(x / (1 - x)))
@@ -84,6 +100,8 @@ class Renderer(nn.Module):
         table = build_subdivision_table(self.smplx_model.faces, self.smplx_model.num_verts, levels)
         g = torch.Generator().manual_seed(int(getattr(self.cfg, "subset_seed", 42)))
         idx = torch.randperm(table.shape[0], generator=g)[: self.num_verts]
+        if getattr(self.cfg, "subset_order", "random") == "spatial":
+            idx = idx[_morton_order(self.smplx_model.v_template.detach().cpu(), torch.as_tensor(table)[idx])]
         self.subset_index = idx  # ids into the densified vertex list (kept for tests)
         self.register_buffer("_gather_idx", torch.as_tensor(table)[idx].contiguous(), persistent=False)
 
