@@ -7,6 +7,11 @@ rendered sequence is reassembled.  On the wire the frames are uint8 RGB (the for
 src/main2.py:351): 786 KB per 512x512 frame instead of 3.1 MB of fp32.
 
 The collective is issued on a side stream, double-buffered, so step k's gather overlaps step k+1's rendering.
+
+The autoregressive token generator does not shard in time.  Two modes: "segment" -- every rank
+rolls its own chain from the same reference tokens and nothing but frames is exchanged; "sequential" -- one rank runs
+the exact chain of the demo loop and hands each rank its block of tokens (send_frames / recv_frames / scatter_frames,
+3.2 MB per frame), so only the rendering scales.
 """
 import torch
 import torch.distributed as dist
@@ -29,6 +34,40 @@ def all_gather_frames(local_frames: torch.Tensor, group=None) -> torch.Tensor:
                       device=local_frames.device)
     dist.all_gather_into_tensor(out, local_frames, group=group)
     return out
+
+
+def send_frames(block: torch.Tensor, dst: int, group=None):
+    """Non-blocking point-to-point send of a contiguous block of per-frame tensors (tokens) to its owner."""
+    return dist.isend(block.contiguous(), dst=dst, group=group)
+
+
+def recv_frames(shape, dtype, device, src: int = 0, group=None) -> torch.Tensor:
+    """Blocking receive of this rank's block (the counterpart of send_frames)."""
+    buf = torch.empty(shape, dtype=dtype, device=device)
+    dist.recv(buf, src=src, group=group)
+    return buf
+
+
+def scatter_frames(full, total_frames: int, trailing_shape, dtype, device, src: int = 0, group=None) -> torch.Tensor:
+    """Rank `src` holds `full` [total_frames, *trailing_shape]; every rank returns its shard_range block.  Point-to-
+    point (the blocks may differ in length by one frame, which scatter() does not allow); xGMI is a full mesh, so the
+    sends leave `src` on distinct links."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if rank == src:
+        if tuple(full.shape) != (total_frames, *trailing_shape):
+            raise ValueError(f"scatter_frames: source holds {tuple(full.shape)}, expected {(total_frames, *trailing_shape)}")
+        pending = []
+        for dst in range(world):
+            s, e = shard_range(total_frames, world, dst)
+            if dst != src:
+                pending.append(send_frames(full[s:e], dst, group))
+        s, e = shard_range(total_frames, world, src)
+        mine = full[s:e].clone()
+        for req in pending:
+            req.wait()
+        return mine
+    s, e = shard_range(total_frames, world, rank)
+    return recv_frames((e - s, *trailing_shape), dtype, device, src, group)
 
 
 class FrameAllGather:

@@ -10,7 +10,8 @@ Only the inference I/O of the boundary is reproduced (SURVEY.md section 8b "call
   * `rollout`       : the demo's window chaining -- every window of T_out frames is generated from the last two
                       outputs of the previous one (main2.py:179-203: `triplanes, smplx_tokens = out[:, -2:]`).
   * `rollout_sharded`: the multi-GPU form: each rank rolls and renders its own contiguous block of windows
-                      (segment-parallel, SURVEY section 8e option i) and the clip is reassembled by an all-gather of
+                      (segment-parallel, SURVEY section 8e option i; `mode="sequential"` = option ii: rank 0 runs the
+                      one exact chain and hands out token blocks) and the clip is reassembled by an all-gather of
                       uint8 frames.
   * `load_reference_checkpoint`: `checkpoint['state_dict']` with the `audio_triplane.` / `triplane_gaussian.renderer.`
                       prefixes (main2.py:127-138, strict=False like the reference).
@@ -23,7 +24,7 @@ import torch.nn as nn
 
 from . import ops
 from .config import ModelConfig
-from .dist import all_gather_frames, shard_range
+from .dist import all_gather_frames, recv_frames, send_frames, shard_range
 from .renderer import Renderer
 from .smplx_decoder import SMPLXDecoder
 from .triplane_audio_net import AudioTriplaneNet
@@ -86,10 +87,26 @@ class AudioDrivenAvatar(nn.Module):
         return {"images": torch.cat(images, dim=1), "triplanes": triplanes, "smplx_tokens": smplx_tokens}
 
     @torch.no_grad()
-    def rollout_sharded(self, triplanes, smplx_tokens, audio_features, cam_params, group=None):
-        """Every rank generates and renders a contiguous block of windows starting from the SAME reference tokens
-        (as training seeds every window from the encoder, lightning_model_wrapper.py:435-466), then the frames are
-        all-gathered as uint8 RGB.  Returns uint8 [world * frames_per_rank, H, W, 3] (batch item 0)."""
+    def rollout_tokens(self, triplanes, smplx_tokens, audio_features, num_windows):
+        """The token side of rollout(): yields (triplane tokens [B,T,C,3R^2], smpl tokens [B,T,D,L]) window by window,
+        chained exactly like main2.py:179-203, without rendering."""
+        T = self.audio_triplane.T_output
+        for w in range(num_windows):
+            tri, smpl = self.audio_triplane.generate_tokens(audio_features[:, w * T:(w + 1) * T], triplanes, smplx_tokens)
+            yield tri, smpl
+            triplanes, smplx_tokens = tri[:, -2:], smpl[:, -2:]
+
+    @torch.no_grad()
+    def rollout_sharded(self, triplanes, smplx_tokens, audio_features, cam_params, group=None, mode="segment"):
+        """Multi-GPU clip: returns uint8 [world * frames_per_rank, H, W, 3] (batch item 0) on every rank.
+
+        mode="segment" (default, SURVEY section 8e option i): every rank generates and renders a contiguous block of
+        windows starting from the SAME reference tokens (as training seeds every window from the encoder,
+        lightning_model_wrapper.py:435-466); only frames are exchanged.
+        mode="sequential" (option ii): rank 0 runs the one exact chain of the demo loop (every window seeded by the
+        previous one) and sends each rank its block of tokens as soon as it exists; ranks render their blocks while
+        rank 0 keeps generating.  Same pixels as rollout() on one GPU; only the rendering scales.
+        """
         import torch.distributed as dist
 
         world, rank = dist.get_world_size(group), dist.get_rank(group)
@@ -100,6 +117,37 @@ class AudioDrivenAvatar(nn.Module):
         w0, w1 = shard_range(windows, world, rank)
         sl = slice(w0 * T, w1 * T)
         cam = {k: v[:, sl] for k, v in cam_params.items()}
-        local = self.rollout(triplanes, smplx_tokens, audio_features[:, sl], cam)["images"]
+        if mode == "segment":
+            local = self.rollout(triplanes, smplx_tokens, audio_features[:, sl], cam)["images"]
+        elif mode == "sequential":
+            if triplanes.shape[0] != 1:
+                raise ValueError("sequential mode shards one clip (batch 1)")
+            per = (w1 - w0) * T
+            net = self.audio_triplane
+            tri_shape = (per, net.cfg.triplane_feature_dim, net.triplane_token_len)
+            smpl_shape = (per, net.cfg.smpl_token_dim, net.smplx_token_len)
+            if rank == 0:
+                mine, pending, block = None, [], []
+                for w, (tri, smpl) in enumerate(self.rollout_tokens(triplanes, smplx_tokens, audio_features, windows)):
+                    block.append((tri[0], smpl[0]))
+                    if (w + 1) % (w1 - w0) == 0:  # a rank's block is complete: hand it over, keep generating
+                        dst = w // (w1 - w0)
+                        tri_b = torch.cat([b[0] for b in block]).contiguous()
+                        smpl_b = torch.cat([b[1] for b in block]).contiguous()
+                        if dst == 0:
+                            mine = (tri_b, smpl_b)
+                        else:
+                            pending += [(send_frames(tri_b, dst, group), tri_b), (send_frames(smpl_b, dst, group), smpl_b)]
+                        block = []
+                for req, _keep in pending:
+                    req.wait()
+                tri_l, smpl_l = mine
+            else:
+                dev, dt = triplanes.device, triplanes.dtype
+                tri_l = recv_frames(tri_shape, dt, dev, 0, group)
+                smpl_l = recv_frames(smpl_shape, dt, dev, 0, group)
+            local = self.renderer(tri_l.unsqueeze(0), cam, smpl_l.unsqueeze(0))[0]
+        else:
+            raise ValueError(f"unknown mode {mode!r}")
         rgba = torch.cat([local[0], torch.ones_like(local[0][..., :1])], dim=-1).contiguous()
         return all_gather_frames(ops.frames_to_rgb8(rgba), group)

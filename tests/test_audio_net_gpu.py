@@ -121,3 +121,38 @@ def test_harness_rollout_chains_windows_like_the_demo_loop():
         second = model.audio_triplane(audio[:, T:], first[3][:, -2:], None, cam1, first[4][:, -2:])
     assert torch.equal(out["images"][:, :T], first[0]) and torch.equal(out["images"][:, T:], second[0])
     assert torch.equal(model.predict_step(tri, smpl, audio[:, :T], cam0), first[0])
+
+
+def test_sequential_multi_gpu_mode_reproduces_the_single_gpu_clip():
+    """rollout_sharded(mode="sequential") on a 1-rank RCCL group: the exact chain, rendered, packed and gathered, must
+    equal rollout() quantised the same way (the N > 1 token hand-out is covered on CPU by tests/test_dist_gloo.py)."""
+    import os
+
+    import torch.distributed as dist
+
+    from audio_motion_avatar_amd import ops
+    from audio_motion_avatar_amd.harness import AudioDrivenAvatar
+    from audio_motion_avatar_amd.synthetic import init_random_heads, make_render_inputs
+
+    cfg = small_cfg()
+    model = AudioDrivenAvatar(cfg)
+    randomize(model.audio_triplane.transformer, 9)
+    init_random_heads(model.renderer)
+    model = model.cuda()
+    B, T, W = 1, 3, 2
+    _, _, cam = make_render_inputs(T * W, cfg.renderer, seed=8, batch=B)
+    g = torch.Generator().manual_seed(4)
+    audio = torch.randn(B, T * W, 48, generator=g).cuda()
+    tri = torch.randn(B, 2, 32, 192, generator=g).cuda()
+    smpl = (torch.randn(B, 2, 32, 10, generator=g) * 0.2).cuda()
+    ref = model.rollout(tri, smpl, audio, cam)["images"][0]
+    want = ops.frames_to_rgb8(torch.cat([ref, torch.ones_like(ref[..., :1])], dim=-1).contiguous())
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("nccl", device_id=torch.device("cuda:0"))
+    try:
+        seq = model.rollout_sharded(tri, smpl, audio, cam, mode="sequential")
+        seg = model.rollout_sharded(tri, smpl, audio, cam, mode="segment")
+    finally:
+        dist.destroy_process_group()
+    assert torch.equal(seq, want)
+    assert torch.equal(seg, want)  # one rank: the segment-parallel clip is the same chain
