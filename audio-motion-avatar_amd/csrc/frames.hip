@@ -1,5 +1,7 @@
 // Frame post-processing for the exchange step: fp32 RGBA -> uint8 RGB, the on-wire format of the all-gather.
 // Quantisation is the reference's own (src/main2.py:351: `(frame * 255).astype(np.uint8)`, i.e. truncation).
+#include <cmath>
+
 #include "amav_common.h"
 
 namespace amav {
@@ -24,9 +26,300 @@ __global__ __launch_bounds__(256) void rgba_to_rgb8_kernel(size_t quads, const f
     out[q] = w;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Tile-sparse wire format of the exchange (lossless).  A rendered avatar frame is mostly background: only the 16x16
+// tiles that differ from the background colour travel, so the all-gather moves ~1/5 of the bytes of dense uint8 RGB.
+//   wire = header (16 int32: magic, count, cap, F, T, H, W, bg) | stored tiles per frame int32[F] | offsets int32[F*T]
+//          (-1 = background tile, else the tile's slot in the payload) | payload [cap][16*16*3] uint8, tiles in
+//          (frame, tile) order
+// pack  : flags -> exclusive scan -> compaction (three launches, no host sync); tiles past `cap` are dropped and
+//         `count` > `cap` tells every receiver (unpack raises its overflow flag; the caller re-packs with more room).
+// unpack: every tile of every gathered buffer is written back into dense [frames, H, W, 3] uint8.
+constexpr int kWireHeaderInts = 16;
+constexpr int kWireMagic = 0x414d4156;  // "AMAV"
+constexpr int kTileBytes = 16 * 16 * 3;
+
+__device__ __forceinline__ unsigned char quant8(float v) { return (unsigned char)(fminf(fmaxf(v, 0.f), 1.f) * 255.0f); }
+
+struct TileGeom {
+    int f, x0, y, cq;  // frame, first pixel column of this lane's quad, pixel row, quad column inside the tile
+};
+__device__ __forceinline__ TileGeom tile_geom(int tile, int gx, int T, int lane) {
+    TileGeom g;
+    g.f = tile / T;
+    const int t = tile - g.f * T;
+    g.cq = lane & 3;
+    g.x0 = (t % gx) * 16 + 4 * g.cq;
+    g.y = (t / gx) * 16 + (lane >> 2);
+    return g;
+}
+
+// this lane's 4 pixels as 12 bytes (3 words); pixels outside the image read as background
+__device__ __forceinline__ uint3 quantise_quad(const float4 *__restrict__ rgba, const TileGeom &g, int H, int W,
+                                               unsigned bgw) {
+    unsigned char b[12];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int x = g.x0 + k;
+        if (x < W && g.y < H) {
+            const float4 p = rgba[((size_t)g.f * H + g.y) * W + x];
+            b[k * 3] = quant8(p.x), b[k * 3 + 1] = quant8(p.y), b[k * 3 + 2] = quant8(p.z);
+        } else {
+            b[k * 3] = bgw & 255u, b[k * 3 + 1] = (bgw >> 8) & 255u, b[k * 3 + 2] = (bgw >> 16) & 255u;
+        }
+    }
+    uint3 w;
+    w.x = b[0] | (b[1] << 8) | (b[2] << 16) | ((unsigned)b[3] << 24);
+    w.y = b[4] | (b[5] << 8) | (b[6] << 16) | ((unsigned)b[7] << 24);
+    w.z = b[8] | (b[9] << 8) | (b[10] << 16) | ((unsigned)b[11] << 24);
+    return w;
+}
+
+__device__ __forceinline__ uint3 background_quad(unsigned bgw) {
+    const unsigned r = bgw & 255u, g = (bgw >> 8) & 255u, b = (bgw >> 16) & 255u;
+    return make_uint3(r | (g << 8) | (b << 16) | (r << 24), g | (b << 8) | (r << 16) | (g << 24),
+                      b | (r << 8) | (g << 16) | (b << 24));
+}
+
+// one wave per tile: flag = the tile differs from the background somewhere
+__global__ __launch_bounds__(256) void tile_flags_kernel(int tiles, int gx, int T, int H, int W,
+                                                         const float4 *__restrict__ rgba, unsigned bgw,
+                                                         int *__restrict__ flags) {
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (tile >= tiles) return;
+    const uint3 q = quantise_quad(rgba, tile_geom(tile, gx, T, lane), H, W, bgw);
+    const uint3 bq = background_quad(bgw);
+    const bool differs = (q.x != bq.x) | (q.y != bq.y) | (q.z != bq.z);
+    const unsigned long long any = __ballot(differs);
+    if (lane == 0) flags[tile] = any ? 1 : 0;
+}
+
+// flags from the caller's hint instead (e.g. the rasterizer's per-tile list lengths: a tile without Gaussians IS
+// background), which saves reading the fp32 frames once
+__global__ __launch_bounds__(256) void tile_hint_kernel(int tiles, const int *__restrict__ hint, int *__restrict__ flags) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < tiles) flags[i] = hint[i] != 0 ? 1 : 0;
+}
+
+// one block per frame: stored tiles of the frame
+__global__ __launch_bounds__(256) void frame_count_kernel(int T, const int *__restrict__ flags,
+                                                          int *__restrict__ frame_counts) {
+    __shared__ int part[4];
+    const int f = blockIdx.x;
+    int c = 0;
+    for (int t = threadIdx.x; t < T; t += 256) c += flags[(size_t)f * T + t];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) frame_counts[f] = part[0] + part[1] + part[2] + part[3];
+}
+
+// one block per frame: flags -> slots (exclusive scan over the whole clip; -1 for background tiles).  The block first
+// sums the counts of the frames before its own, then scans its own T flags; the last block writes the clip total.
+__global__ __launch_bounds__(1024) void tile_scan_kernel(int F, int T, int cap, int *__restrict__ header,
+                                                         const int *__restrict__ frame_counts,
+                                                         int *__restrict__ offsets) {
+    __shared__ int wave_tot[16];
+    __shared__ int carry;
+    const int f = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int mine = 0;
+    for (int g = threadIdx.x; g < f; g += 1024) mine += frame_counts[g];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+    if (lane == 0) wave_tot[wave] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int b = 0;
+        for (int w = 0; w < 16; ++w) b += wave_tot[w];
+        carry = b;
+    }
+    __syncthreads();
+    int *off = offsets + (size_t)f * T;
+    for (int base = 0; base < T; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int fl = i < T ? off[i] : 0;
+        int incl = fl;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += up;
+        }
+        __syncthreads();  // wave_tot / carry of the previous round have been read
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        int before = carry;
+        for (int w = 0; w < wave; ++w) before += wave_tot[w];
+        if (i < T) off[i] = fl ? before + incl - fl : -1;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = before + incl;
+    }
+    __syncthreads();
+    if (f == F - 1 && threadIdx.x == 0) header[1] = carry, header[2] = cap;
+}
+
+__global__ void wire_header_kernel(int *header, int F, int T, int H, int W, int bgw) {
+    if (threadIdx.x == 0) header[0] = kWireMagic, header[3] = F, header[4] = T, header[5] = H, header[6] = W, header[7] = bgw;
+}
+
+__global__ __launch_bounds__(256) void tile_compact_kernel(int tiles, int gx, int T, int H, int W, int cap,
+                                                           const float4 *__restrict__ rgba, unsigned bgw,
+                                                           const int *__restrict__ offsets,
+                                                           unsigned *__restrict__ payload) {
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (tile >= tiles) return;
+    const int off = offsets[tile];
+    if (off < 0 || off >= cap) return;
+    const uint3 q = quantise_quad(rgba, tile_geom(tile, gx, T, lane), H, W, bgw);
+    unsigned *dst = payload + (size_t)off * (kTileBytes / 4) + lane * 3;
+    dst[0] = q.x, dst[1] = q.y, dst[2] = q.z;
+}
+
+// grid over (buffer, tile): dense frames out.  status[0] |= 1 when a sender dropped tiles (count > cap)
+__global__ __launch_bounds__(256) void tile_unpack_kernel(int buffers, int tiles, int gx, int T, int H, int W, int cap,
+                                                          const unsigned char *__restrict__ wire, size_t wire_stride,
+                                                          unsigned char *__restrict__ out, int *__restrict__ status) {
+    const long long gt = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (gt >= (long long)buffers * tiles) return;
+    const int b = (int)(gt / tiles), tile = (int)(gt - (long long)b * tiles);
+    const unsigned char *buf = wire + (size_t)b * wire_stride;
+    const int *header = reinterpret_cast<const int *>(buf);
+    const int F = tiles / T;
+    const int *offsets = header + kWireHeaderInts + F;
+    const size_t pay_at = ((size_t)(kWireHeaderInts + F + tiles) * 4 + 15) / 16 * 16;
+    const unsigned *payload = reinterpret_cast<const unsigned *>(buf + pay_at);
+    const unsigned bgw = (unsigned)header[7];
+    const int off = offsets[tile];
+    if (lane == 0 && tile == 0 && (header[0] != kWireMagic || header[1] > cap)) atomicOr(status, 1);
+    uint3 q = background_quad(bgw);
+    if (off >= 0 && off < cap) {
+        const unsigned *src = payload + (size_t)off * (kTileBytes / 4) + lane * 3;
+        q = make_uint3(src[0], src[1], src[2]);
+    }
+    const TileGeom g = tile_geom(tile, gx, T, lane);
+    if (g.y >= H || g.x0 >= W) return;
+    unsigned char *dst = out + ((((size_t)b * F + g.f) * H + g.y) * W + g.x0) * 3;
+    if (g.x0 + 3 < W && (W & 3) == 0) {
+        unsigned *d = reinterpret_cast<unsigned *>(dst);
+        d[0] = q.x, d[1] = q.y, d[2] = q.z;
+    } else {
+        const unsigned w3[3] = {q.x, q.y, q.z};
+        for (int k = 0; k < 12 && g.x0 + k / 3 < W; ++k) dst[k] = (w3[k >> 2] >> (8 * (k & 3))) & 255u;
+    }
+}
+
+// Row form of the unpack for widths that are multiples of 16 pixels: one thread per 16-byte chunk of an output row, so
+// the stores of a wave are one contiguous kilobyte.  A chunk lies inside one tile row (48 bytes, 16-byte aligned).
+__global__ __launch_bounds__(256) void tile_unpack_rows_kernel(long long chunks, int F, int gx, int T, int H, int W,
+                                                               int cap, const unsigned char *__restrict__ wire,
+                                                               size_t wire_stride, uint4 *__restrict__ out,
+                                                               int *__restrict__ status) {
+    const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= chunks) return;
+    const int per_row = W * 3 / 16;                 // chunks per pixel row = 3 per tile
+    const int j = (int)(id % per_row);
+    const long long row = id / per_row;             // (buffer * F + frame) * H + y
+    const int y = (int)(row % H);
+    const long long bf = row / H;
+    const int f = (int)(bf % F), b = (int)(bf / F);
+    const int tx = j / 3, part = j - tx * 3;
+    const int tile = f * T + (y >> 4) * gx + tx;
+    const unsigned char *buf = wire + (size_t)b * wire_stride;
+    const int *header = reinterpret_cast<const int *>(buf);
+    const int off = header[kWireHeaderInts + F + tile];
+    if (id % ((long long)per_row * H * F) == 0 && (header[0] != kWireMagic || header[1] > cap)) atomicOr(status, 1);
+    uint4 v;
+    if (off >= 0 && off < cap) {
+        const size_t pay_at = ((size_t)(kWireHeaderInts + F + F * T) * 4 + 15) / 16 * 16;
+        v = *reinterpret_cast<const uint4 *>(buf + pay_at + (size_t)off * kTileBytes + (y & 15) * 48 + part * 16);
+    } else {
+        const unsigned bgw = (unsigned)header[7];
+        const unsigned c[3] = {bgw & 255u, (bgw >> 8) & 255u, (bgw >> 16) & 255u};
+        unsigned w4[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {  // byte n of the chunk is channel (16 * part + n) % 3
+            const int n0 = 16 * part + 4 * k;
+            w4[k] = c[n0 % 3] | (c[(n0 + 1) % 3] << 8) | (c[(n0 + 2) % 3] << 16) | (c[(n0 + 3) % 3] << 24);
+        }
+        v = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+    }
+    out[id] = v;
+}
+
+static size_t wire_payload_at(int F, int tiles) { return ((size_t)(kWireHeaderInts + F + tiles) * 4 + 15) / 16 * 16; }
+
 }  // namespace amav
 
 using namespace amav;
+
+extern "C" size_t amav_frames_wire_bytes(int F, int H, int W, int64_t cap_tiles) {
+    if (F <= 0 || H <= 0 || W <= 0 || cap_tiles < 0) return 0;
+    const long long tiles = (long long)F * ((H + 15) / 16) * ((W + 15) / 16);
+    if (tiles > 0x7fffffffLL - kWireHeaderInts || cap_tiles > tiles) return 0;
+    return (wire_payload_at(F, (int)tiles) + (size_t)cap_tiles * kTileBytes + 15) / 16 * 16;
+}
+
+static unsigned pack_bg(const float *bg) {
+    auto q = [](float v) { return (unsigned)(unsigned char)(std::fmin(std::fmax(v, 0.f), 1.f) * 255.0f); };
+    return q(bg[0]) | (q(bg[1]) << 8) | (q(bg[2]) << 16);
+}
+
+extern "C" int amav_frames_pack_tiles(int F, int H, int W, const float *rgba, const float *bg_host3,
+                                      const int32_t *tile_hint, int64_t cap_tiles, void *wire, size_t wire_bytes,
+                                      void *stream_) {
+    AMAV_REQUIRE(F > 0 && H > 0 && W > 0 && cap_tiles >= 0, "amav_frames_pack_tiles: bad sizes F=%d H=%d W=%d", F, H, W);
+    AMAV_REQUIRE(rgba && bg_host3 && wire, "amav_frames_pack_tiles: NULL pointer");
+    AMAV_REQUIRE(((reinterpret_cast<uintptr_t>(rgba) | reinterpret_cast<uintptr_t>(wire)) & 15) == 0,
+                 "amav_frames_pack_tiles: misaligned buffer");
+    const size_t need = amav_frames_wire_bytes(F, H, W, cap_tiles);
+    AMAV_REQUIRE(need != 0, "amav_frames_pack_tiles: capacity %lld exceeds the tile count", (long long)cap_tiles);
+    if (wire_bytes < need) return fail(AMAV_ERR_WORKSPACE, "amav_frames_pack_tiles: wire buffer %zu < %zu", wire_bytes, need);
+    const int gx = (W + 15) / 16, T = gx * ((H + 15) / 16), tiles = F * T;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const unsigned bgw = pack_bg(bg_host3);
+    int *header = static_cast<int *>(wire), *frame_counts = header + kWireHeaderInts, *offsets = frame_counts + F;
+    if (hipMemsetAsync(header, 0, (size_t)kWireHeaderInts * 4, stream) != hipSuccess)
+        return fail(AMAV_ERR_LAUNCH, "amav_frames_pack_tiles: hipMemsetAsync failed");
+    const float4 *px = reinterpret_cast<const float4 *>(rgba);
+    const unsigned grid = (unsigned)((tiles + 3) / 4);
+    if (tile_hint)
+        tile_hint_kernel<<<(unsigned)((tiles + 255) / 256), 256, 0, stream>>>(tiles, tile_hint, offsets);
+    else
+        tile_flags_kernel<<<grid, 256, 0, stream>>>(tiles, gx, T, H, W, px, bgw, offsets);
+    frame_count_kernel<<<F, 256, 0, stream>>>(T, offsets, frame_counts);
+    tile_scan_kernel<<<F, 1024, 0, stream>>>(F, T, (int)cap_tiles, header, frame_counts, offsets);
+    wire_header_kernel<<<1, 64, 0, stream>>>(header, F, T, H, W, (int)bgw);
+    if (cap_tiles > 0)
+        tile_compact_kernel<<<grid, 256, 0, stream>>>(tiles, gx, T, H, W, (int)cap_tiles, px, bgw, offsets,
+                                                      reinterpret_cast<unsigned *>(static_cast<unsigned char *>(wire) +
+                                                                                   wire_payload_at(F, tiles)));
+    return check_launch("amav_frames_pack_tiles");
+}
+
+extern "C" int amav_frames_unpack_tiles(int num_buffers, int F, int H, int W, int64_t cap_tiles, const void *wire_all,
+                                        size_t wire_stride, uint8_t *out_rgb8, int32_t *status, void *stream_) {
+    AMAV_REQUIRE(num_buffers > 0 && F > 0 && H > 0 && W > 0 && cap_tiles >= 0, "amav_frames_unpack_tiles: bad sizes");
+    AMAV_REQUIRE(wire_all && out_rgb8 && status, "amav_frames_unpack_tiles: NULL pointer");
+    const size_t need = amav_frames_wire_bytes(F, H, W, cap_tiles);
+    AMAV_REQUIRE(need != 0 && wire_stride >= need && wire_stride % 16 == 0,
+                 "amav_frames_unpack_tiles: wire stride %zu does not hold a %zu-byte buffer", wire_stride, need);
+    AMAV_REQUIRE((reinterpret_cast<uintptr_t>(wire_all) & 15) == 0 && (reinterpret_cast<uintptr_t>(out_rgb8) & 3) == 0,
+                 "amav_frames_unpack_tiles: misaligned buffer");
+    const int gx = (W + 15) / 16, T = gx * ((H + 15) / 16), tiles = F * T;
+    if (W % 16 == 0 && (reinterpret_cast<uintptr_t>(out_rgb8) & 15) == 0) {
+        const long long chunks = (long long)num_buffers * F * H * (W * 3 / 16);
+        tile_unpack_rows_kernel<<<(unsigned)((chunks + 255) / 256), 256, 0, static_cast<hipStream_t>(stream_)>>>(
+            chunks, F, gx, T, H, W, (int)cap_tiles, static_cast<const unsigned char *>(wire_all), wire_stride,
+            reinterpret_cast<uint4 *>(out_rgb8), status);
+        return check_launch("amav_frames_unpack_tiles");
+    }
+    const long long total = (long long)num_buffers * tiles;
+    tile_unpack_kernel<<<(unsigned)((total + 3) / 4), 256, 0, static_cast<hipStream_t>(stream_)>>>(
+        num_buffers, tiles, gx, T, H, W, (int)cap_tiles, static_cast<const unsigned char *>(wire_all), wire_stride,
+        out_rgb8, status);
+    return check_launch("amav_frames_unpack_tiles");
+}
 
 extern "C" int amav_frames_to_rgb8(int64_t num_pixels, const float *rgba, uint8_t *out_rgb8, void *stream) {
     AMAV_REQUIRE(num_pixels > 0 && num_pixels % 4 == 0, "amav_frames_to_rgb8: pixel count %lld not a multiple of 4",

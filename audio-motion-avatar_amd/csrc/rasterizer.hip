@@ -1082,6 +1082,31 @@ extern "C" int amav_rasterize_forward(const amav_raster_args *a, void *stream_) 
     return check_launch("amav_rasterize_forward");
 }
 
+namespace amav {
+namespace raster {
+__global__ __launch_bounds__(256) void tile_counts_kernel(int F, int T, const Status *__restrict__ st,
+                                                          const int *__restrict__ tile_off, int *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= F * T) return;
+    const int f = i / T, t = i - f * T;
+    const int *off = tile_off + (size_t)f * (T + 1);
+    out[i] = st->overflow ? 1 : off[t + 1] - off[t];  // after an overflow nothing is known: every tile "may be drawn"
+}
+}  // namespace raster
+}  // namespace amav
+
+extern "C" int amav_rasterize_tile_counts(const void *workspace, int F, int N, int H, int W, int64_t capacity,
+                                          int32_t *out_counts, void *stream_) {
+    AMAV_REQUIRE(workspace && out_counts, "amav_rasterize_tile_counts: NULL pointer");
+    AMAV_REQUIRE(F > 0 && N > 0 && H > 0 && W > 0 && capacity >= 0, "amav_rasterize_tile_counts: bad sizes");
+    const int gx = (W + kTile - 1) / kTile, gy = (H + kTile - 1) / kTile, T = gx * gy;
+    size_t bytes = 0;
+    const Buffers b = carve(const_cast<void *>(workspace), F, N, T, capacity / F * F, &bytes);
+    tile_counts_kernel<<<(unsigned)(((long long)F * T + 255) / 256), 256, 0, static_cast<hipStream_t>(stream_)>>>(
+        F, T, b.status, b.tile_off, out_counts);
+    return check_launch("amav_rasterize_tile_counts");
+}
+
 extern "C" int amav_rasterize_status(const void *workspace, int64_t *total, int64_t *max_frame, int32_t *overflow,
                                      void *stream_) {
     AMAV_REQUIRE(workspace != nullptr, "amav_rasterize_status: workspace is NULL");

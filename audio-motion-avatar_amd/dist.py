@@ -4,7 +4,9 @@ One process per GPU; `torch.distributed` backend "nccl" is RCCL on ROCm (xGMI in
 independent from SMPL-X decode to rasterisation (the reference renders them in a per-frame loop,
 src/models/renderer.py:475-477), so each rank owns a contiguous block of frames and nothing is exchanged until the
 rendered sequence is reassembled.  On the wire the frames are uint8 RGB (the format the reference writes to video,
-src/main2.py:351): 786 KB per 512x512 frame instead of 3.1 MB of fp32.
+src/main2.py:351): 786 KB per 512x512 frame instead of 3.1 MB of fp32 -- and by default only their non-background
+16x16 tiles (lossless; see FrameAllGather), because at ~200 k frames/s per GPU the dense frames alone would need more
+than the seven xGMI links of a GPU deliver.
 
 The collective is issued on a side stream, double-buffered, so step k's gather overlaps step k+1's rendering.
 
@@ -71,29 +73,89 @@ def scatter_frames(full, total_frames: int, trailing_shape, dtype, device, src: 
 
 
 class FrameAllGather:
-    """Pack (HIP) + all-gather (RCCL) of a shard's frames on a side stream, two buffers deep."""
+    """Pack (HIP) + all-gather (RCCL) of a shard's frames on a side stream, two buffers deep.
 
-    def __init__(self, frames, height, width, world_size, device, group=None):
+    wire="sparse" (default): only the 16x16 tiles that differ from the background travel (ops.frames_pack_tiles), and
+    every rank unpacks the gathered buffers back into dense uint8 frames -- lossless, ~1/5 of the bytes for an avatar
+    clip.  The per-rank tile capacity is fixed by calibrate() (a synchronising call, made once before the timed
+    region: max stored tiles over the ranks + 25 %); a later step that needs more sets `overflowed()`, exactly like
+    the rasterizer's instance capacity.  wire="dense": plain uint8 RGB frames (ops.frames_to_rgb8).
+    """
+
+    def __init__(self, frames, height, width, world_size, device, group=None, wire="sparse", bg=(1.0, 1.0, 1.0)):
+        if wire not in ("sparse", "dense"):
+            raise ValueError(f"wire must be 'sparse' or 'dense', got {wire!r}")
         self.group = group
         self.world = world_size
+        self.frames, self.height, self.width = frames, height, width
+        self.device = device
+        self.wire = wire
+        self.bg = tuple(float(c) for c in bg)
         self.stream = torch.cuda.Stream(device=device)
-        self.local = [torch.empty(frames, height, width, 3, dtype=torch.uint8, device=device) for _ in range(2)]
         self.full = [torch.empty(world_size * frames, height, width, 3, dtype=torch.uint8, device=device)
                      for _ in range(2)]
         self.turn = 0
+        if wire == "dense":
+            self.local = [torch.empty(frames, height, width, 3, dtype=torch.uint8, device=device) for _ in range(2)]
+        else:
+            self.capacity = None
+            self.status = torch.zeros(1, dtype=torch.int32, device=device)
 
-    def submit(self, rgba: torch.Tensor) -> torch.Tensor:
-        """rgba: contiguous fp32 [..., H, W, 4] produced on the current stream.  Returns the (future) full sequence
-        [world * F, H, W, 3] uint8; call wait() before reading it on the current stream."""
+    # ---- sparse wire -------------------------------------------------------------------------------------------------
+    def calibrate(self, rgba: torch.Tensor, headroom=1.25, tile_hint=None):
+        """Size the per-rank wire buffers from one rendered shard (host sync + a MAX all-reduce: call it in warm-up).
+        Pass the same kind of `tile_hint` the steps will pass to submit(): a hint stores a superset of the tiles."""
         from . import ops
 
+        if self.wire != "sparse":
+            return None
+        F, H, W = self.frames, self.height, self.width
+        count, _ = ops.frames_wire_count(ops.frames_pack_tiles(rgba.view(F, H, W, 4), 0, self.bg, tile_hint=tile_hint))
+        t = torch.tensor([count], dtype=torch.int64, device=self.device)
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        tiles = F * ((H + 15) // 16) * ((W + 15) // 16)
+        self.capacity = min(tiles, int(int(t.item()) * headroom) + 64)
+        nbytes = ops.frames_wire_bytes(F, H, W, self.capacity)
+        self.local = [torch.empty(nbytes, dtype=torch.uint8, device=self.device) for _ in range(2)]
+        self.gathered = [torch.empty(self.world, nbytes, dtype=torch.uint8, device=self.device) for _ in range(2)]
+        self.status.zero_()
+        return self.capacity
+
+    def wire_bytes_per_rank(self):
+        return int(self.local[0].numel())
+
+    def overflowed(self) -> bool:
+        """True when some step since calibrate() had more non-background tiles than the wire holds (synchronises)."""
+        return self.wire == "sparse" and bool(int(self.status.item()))
+
+    # ---- one step ------------------------------------------------------------------------------------------------------
+    def submit(self, rgba: torch.Tensor, tile_hint=None) -> torch.Tensor:
+        """rgba: contiguous fp32 [..., H, W, 4] produced on the current stream.  Returns the (future) full sequence
+        [world * F, H, W, 3] uint8; call wait() before reading it on the current stream.  `tile_hint` (sparse wire):
+        int32 [F * tiles], zero where the tile is known to be background (RasterWorkspace.tile_counts()), which saves
+        one pass over the fp32 frames."""
+        from . import ops
+
+        if self.wire == "sparse" and self.capacity is None:
+            raise RuntimeError("FrameAllGather(wire='sparse'): call calibrate() once before submit()")
         i = self.turn
         self.turn ^= 1
+        F, H, W = self.frames, self.height, self.width
         self.stream.wait_stream(torch.cuda.current_stream())
         rgba.record_stream(self.stream)
+        if tile_hint is not None:
+            tile_hint.record_stream(self.stream)
         with torch.cuda.stream(self.stream):
-            ops.frames_to_rgb8(rgba.view(self.local[i].shape[:-1] + (4,)), out=self.local[i])
-            dist.all_gather_into_tensor(self.full[i], self.local[i], group=self.group)
+            if self.wire == "dense":
+                ops.frames_to_rgb8(rgba.view(F, H, W, 4), out=self.local[i])
+                dist.all_gather_into_tensor(self.full[i], self.local[i], group=self.group)
+            else:
+                ops.frames_pack_tiles(rgba.view(F, H, W, 4), self.capacity, self.bg, wire=self.local[i],
+                                      tile_hint=tile_hint)
+                dist.all_gather_into_tensor(self.gathered[i], self.local[i], group=self.group)
+                ops.frames_unpack_tiles(self.gathered[i], self.world, F, H, W, self.capacity, out=self.full[i],
+                                        status=self.status)
         return self.full[i]
 
     def wait(self):

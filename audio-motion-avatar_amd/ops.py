@@ -103,6 +103,16 @@ class RasterWorkspace:
             raise AmavError(f"amav_rasterize_workspace_bytes rejected {self.key} capacity={self.capacity}")
         self.buffer = torch.empty(nbytes, dtype=torch.uint8, device=device)
 
+    def tile_counts(self, out=None):
+        """Per-tile Gaussian list lengths of the last forward, int32 [F * tiles] (no host sync)."""
+        F, N, H, W = self.key
+        n = F * ((H + 15) // 16) * ((W + 15) // 16)
+        if out is None:
+            out = torch.empty(n, dtype=torch.int32, device=self.buffer.device)
+        check(_lib.lib().amav_rasterize_tile_counts(self.buffer.data_ptr(), F, N, H, W, self.capacity, out.data_ptr(),
+                                                    _stream()), "amav_rasterize_tile_counts")
+        return out
+
     def status(self):
         """(total_instances, overflowed) of the last forward.  Synchronises the current stream."""
         total, _, over = self.status_full()
@@ -213,6 +223,64 @@ def frames_to_rgb8(rgba, out=None):
     check(_lib.lib().amav_frames_to_rgb8(rgba.numel() // 4, rgba.data_ptr(), out.data_ptr(), _stream()),
           "amav_frames_to_rgb8")
     return out
+
+
+def frames_wire_bytes(F, H, W, capacity_tiles):
+    n = _lib.lib().amav_frames_wire_bytes(int(F), int(H), int(W), int(capacity_tiles))
+    if n == 0:
+        raise AmavError(f"frames_wire_bytes: bad sizes F={F} H={H} W={W} capacity={capacity_tiles}")
+    return int(n)
+
+
+def frames_pack_tiles(rgba, capacity_tiles, bg=(1.0, 1.0, 1.0), wire=None, tile_hint=None):
+    """fp32 RGBA [F,H,W,4] -> tile-sparse wire buffer (uint8 tensor, include/amav.h).  No host sync; use
+    frames_wire_count() (which synchronises) to read how many tiles were stored.  `tile_hint`: int32 [F*tiles], zero
+    where the caller knows the tile is background (RasterWorkspace.tile_counts())."""
+    rgba = _need(rgba, "rgba")
+    if rgba.dim() != 4 or rgba.shape[-1] != 4 or not rgba.is_contiguous() or rgba.dtype != torch.float32:
+        raise AmavError("frames_pack_tiles: need a contiguous fp32 [F,H,W,4] tensor")
+    F, H, W = (int(x) for x in rgba.shape[:3])
+    need = frames_wire_bytes(F, H, W, capacity_tiles)
+    if wire is None:
+        wire = torch.empty(need, dtype=torch.uint8, device=rgba.device)
+    elif wire.dtype != torch.uint8 or not wire.is_contiguous() or wire.numel() < need:
+        raise AmavError(f"frames_pack_tiles: wire must be a contiguous uint8 buffer of >= {need} bytes")
+    bg3 = (ctypes.c_float * 3)(*[float(c) for c in bg])
+    hint_ptr = None
+    if tile_hint is not None:
+        tile_hint = _need(tile_hint, "tile_hint", torch.int32)
+        if not tile_hint.is_contiguous() or tile_hint.numel() != F * ((H + 15) // 16) * ((W + 15) // 16):
+            raise AmavError("frames_pack_tiles: tile_hint must be a contiguous int32 [F * tiles] tensor")
+        hint_ptr = tile_hint.data_ptr()
+    check(_lib.lib().amav_frames_pack_tiles(F, H, W, rgba.data_ptr(), bg3, hint_ptr, int(capacity_tiles),
+                                            wire.data_ptr(), wire.numel(), _stream()), "amav_frames_pack_tiles")
+    return wire
+
+
+def frames_wire_count(wire):
+    """(stored tiles, capacity) of a packed wire buffer; synchronises."""
+    head = wire[:16].view(torch.int32).cpu()
+    return int(head[1]), int(head[2])
+
+
+def frames_unpack_tiles(wire_all, num_buffers, F, H, W, capacity_tiles, out=None, status=None):
+    """`num_buffers` gathered wire buffers (a uint8 tensor [num_buffers, stride]) -> uint8 RGB [num_buffers*F,H,W,3].
+    `status` (int32 [1], accumulated) becomes non-zero when a sender had to drop tiles."""
+    wire_all = _need(wire_all, "wire_all", torch.uint8)
+    if wire_all.dtype != torch.uint8 or not wire_all.is_contiguous() or wire_all.dim() != 2 or \
+            wire_all.shape[0] != num_buffers:
+        raise AmavError("frames_unpack_tiles: wire_all must be a contiguous uint8 [num_buffers, stride] tensor")
+    dev = wire_all.device
+    if out is None:
+        out = torch.empty(num_buffers * F, H, W, 3, dtype=torch.uint8, device=dev)
+    elif tuple(out.shape) != (num_buffers * F, H, W, 3) or out.dtype != torch.uint8 or not out.is_contiguous():
+        raise AmavError(f"frames_unpack_tiles: out must be contiguous uint8 {(num_buffers * F, H, W, 3)}")
+    if status is None:
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+    check(_lib.lib().amav_frames_unpack_tiles(int(num_buffers), int(F), int(H), int(W), int(capacity_tiles),
+                                              wire_all.data_ptr(), wire_all.shape[1], out.data_ptr(), status.data_ptr(),
+                                              _stream()), "amav_frames_unpack_tiles")
+    return out, status
 
 
 # ------------------------------------------------------------------------------------------------------------ LBS

@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the workload timed on the CPU oracle")
     ap.add_argument("--chunks", type=int, default=1,
                     help="frame groups pipelined on separate HIP streams (1 is fastest; 2 costs 17 percent more time, 4 costs 56 percent)")
+    ap.add_argument("--wire", choices=["sparse", "dense"], default="sparse",
+                    help="N > 1 exchange format: non-background 16x16 tiles of the uint8 frames (lossless) or all of them")
     ap.add_argument("--workload", choices=["render", "full"], default="render",
                     help="render = BASELINE configs[1] (static decode + LBS + rasterize, the metric's config); "
                          "full = configs[2]: synthetic audio tokens -> AudioTriplaneNet (autoregressive) -> SMPL-X "
@@ -103,7 +105,7 @@ def run_full_workload(args, device, world, rank, dist):
     smpl_tok = (torch.randn(1, 2, 256, 80, generator=g) * 0.1).to(device)
     _, _, cam = make_render_inputs(F, rcfg, seed=42 + rank, device=device)
     workspaces = [None] * max(1, min(args.chunks, F))
-    gather = FrameAllGather(F, H, W, world, device) if dist is not None else None
+    gather = FrameAllGather(F, H, W, world, device, wire=args.wire) if dist is not None else None
 
     def step():
         with torch.no_grad():
@@ -113,8 +115,9 @@ def run_full_workload(args, device, world, rank, dist):
             params = {k: v.reshape(B, T, *v.shape[1:]) for k, v in params.items()}
             rgba, _ = renderer.render_tokens(out_tri[0], params, cam, chunks=args.chunks, workspaces=workspaces,
                                              check_overflow=False)
-        if gather is not None:
-            gather.submit(rgba)
+        if gather is not None and (gather.wire == "dense" or gather.capacity is not None):
+            hint = workspaces[0].tile_counts() if gather.wire == "sparse" and len(workspaces) == 1 else None
+            gather.submit(rgba, tile_hint=hint)
         return rgba
 
     step()  # sizes the rasterizer workspaces (the only host sync of the path is this deferred overflow check)
@@ -123,6 +126,10 @@ def run_full_workload(args, device, world, rank, dist):
         if over:
             fc, n, h, w = ws.key
             workspaces[ci] = ops.RasterWorkspace(fc, n, h, w, int(fc * max_frame * 1.25), device)
+    if gather is not None:  # size the exchange buffers from one good step (host sync + MAX all-reduce, untimed)
+        first = step()
+        gather.calibrate(first, tile_hint=workspaces[0].tile_counts() if len(workspaces) == 1 else None)
+        del first
     for _ in range(args.warmup):
         step()
     if gather is not None:
@@ -146,6 +153,7 @@ def run_full_workload(args, device, world, rank, dist):
     status = [ws.status() for ws in workspaces]
     total = sum(s[0] for s in status)
     assert not any(s[1] for s in status), "rasterizer workspace overflowed inside the timed region"
+    assert gather is None or not gather.overflowed(), "exchange wire buffer overflowed inside the timed region"
     finite = bool(torch.isfinite(rgba).all())
     result = {
         "metric": "rendered frames/sec @512x512, 10k Gaussians (audio tokens -> AudioTriplaneNet -> SMPL-X LBS -> "
@@ -157,13 +165,24 @@ def run_full_workload(args, device, world, rank, dist):
                                "S=6304, autoregressive) -> SMPLXDecoder -> LBS -> decode -> rasterize 250 x 512x512",
                    "frames_per_gpu_per_step": F, "gaussians": N, "image": [H, W], "weights": "random init (transformer.proj_out scaled by 0.02 so the AR chain stays bounded)",
                    "instances_per_step": int(total), "output_finite": finite,
-                   "exchange": "all-gather of uint8 RGB frames over RCCL" if world > 1 else "none"},
+                   "exchange": exchange_description(gather)},
         "roofline": {"bound": "mfma", "kernel": "selfattn_kernel (fp32 MFMA flash attention)", "achieved": None,
                      "peak": 157.3, "unit": "TFLOP/s", "frac": None, "traffic": None,
                      "note": "see tools/bench_attention.py and profiles/ for the kernel-level number"},
     }
     if rank == 0:
-        print(json.dumps(result))
+        emit(result)
+
+
+def exchange_description(gather):
+    if gather is None:
+        return "none"
+    if gather.wire == "dense":
+        return {"collective": "RCCL all-gather of uint8 RGB frames", "bytes_per_rank_per_step": int(gather.local[0].numel())}
+    return {"collective": "RCCL all-gather of the non-background 16x16 tiles of the uint8 RGB frames (lossless), "
+                          "unpacked to dense frames on every rank",
+            "bytes_per_rank_per_step": gather.wire_bytes_per_rank(), "capacity_tiles": gather.capacity,
+            "dense_bytes_per_rank_per_step": gather.frames * gather.height * gather.width * 3}
 
 
 def host_cores():
@@ -238,6 +257,11 @@ def cpu_baseline_and_parity(renderer, cfg, tokens, smpl, cam, step_outputs, n_fr
     return base, parity
 
 
+def emit(result):
+    """The one JSON line of the contract, on the process's original stdout."""
+    os.write(JSON_FD, (json.dumps(result) + "\n").encode())
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -275,7 +299,7 @@ def main():
     tokens, smpl, cam = make_render_inputs(F, cfg, seed=42 + rank, device=device)
     smpl_tokens = torch.zeros(1, F, 1, 1, device=device)  # only its [B,T] shape is read when no decoder is attached
     workspaces = [None] * max(1, min(args.chunks, F))  # filled by the first step, then reused
-    gather = FrameAllGather(F, H, W, world, device) if dist is not None else None
+    gather = FrameAllGather(F, H, W, world, device, wire=args.wire) if dist is not None else None
 
     import audio_motion_avatar_amd.renderer as R
 
@@ -302,6 +326,9 @@ def main():
         rgba = step()
         assert not any(ws.status()[1] for ws in workspaces)
         assert torch.equal(ref_img, rgba[..., :3]), "pinned-workspace step differs from Renderer.forward"
+        if gather is not None:
+            # sizes the wire buffers (host sync + MAX all-reduce, outside the timed region)
+            gather.calibrate(rgba, tile_hint=workspaces[0].tile_counts() if len(workspaces) == 1 else None)
         del ref_img, rgba
 
     nchunks = len(workspaces)
@@ -311,8 +338,9 @@ def main():
         ops.PROFILE_EVENTS = list(events[i]) if i is not None else None
         with torch.no_grad():
             out = step()
-        if gather is not None:
-            gather.submit(out)  # uint8 pack + RCCL all-gather on a side stream, overlapping the next step
+        if gather is not None:  # pack + RCCL all-gather (+ unpack) on a side stream, overlapping the next step
+            hint = workspaces[0].tile_counts() if gather.wire == "sparse" and len(workspaces) == 1 else None
+            gather.submit(out, tile_hint=hint)
         return out
 
     for _ in range(args.warmup):
@@ -339,6 +367,7 @@ def main():
     status = [ws.status() for ws in workspaces]
     total = sum(s[0] for s in status)
     assert not any(s[1] for s in status), "rasterizer workspace overflowed inside the timed region"
+    assert gather is None or not gather.overflowed(), "exchange wire buffer overflowed inside the timed region"
 
     # blend-kernel time per step = sum over the step's frame groups (one launch each)
     blend_ms = sorted(sum(s.elapsed_ms(e) for s, e in step_events) for step_events in events)
@@ -364,7 +393,7 @@ def main():
                                "no audio net", "frames_per_gpu_per_step": F, "gaussians": N, "image": [H, W],
                    "triplane": [cfg.triplane_feature_dim, cfg.triplane_resolution],
                    "instances_per_step": int(total), "stream_pipelined_frame_groups": len(workspaces),
-                   "exchange": "all-gather of uint8 RGB frames over RCCL" if dist is not None else "none"},
+                   "exchange": exchange_description(gather)},
         "roofline": {"bound": "hbm", "kernel": "render_kernel (tile blend)", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": pmc_traffic_bytes("render_kernel") if (F, N, H) == (250, 10000, 512) else None,
@@ -375,10 +404,14 @@ def main():
         result["cpu_baseline"] = base
         result["parity"] = parity
     if rank == 0:
-        print(json.dumps(result))
+        emit(result)
     if dist is not None:
         dist.destroy_process_group()
 
 
 if __name__ == "__main__":
+    # RCCL prints its version banner on stdout when the communicator is created: keep the original stdout for the JSON
+    # line only and send everything else (C libraries included) to stderr
+    JSON_FD = os.dup(1)
+    os.dup2(2, 1)
     main()

@@ -123,6 +123,32 @@ int amav_rasterize_status(const void *workspace, int64_t *total_instances, int64
  * reference's own quantisation (src/main2.py:351: (frame * 255).astype(uint8), truncating). num_pixels % 4 == 0. */
 int amav_frames_to_rgb8(int64_t num_pixels, const float *rgba_dev, uint8_t *out_rgb8_dev, void *stream);
 
+/* Tile-sparse form of the same exchange (lossless): an avatar frame is mostly background, so only the 16x16 tiles
+ * that differ from the background colour are put on the wire.  One wire buffer per rank:
+ *   int32 header[16] = {magic, stored tiles, capacity, F, tiles per frame, H, W, background as 0x00BBGGRR, 0...}
+ *   int32 stored tiles per frame [F]
+ *   int32 slot of every tile [F * tiles per frame]   (-1: background; else index into the payload)
+ *   uint8 payload [capacity][16*16*3]                (16-byte aligned; tiles in (frame, tile) order)
+ * amav_frames_wire_bytes: size of such a buffer (0 on bad arguments).
+ * amav_frames_pack_tiles: fp32 RGBA frames [F,H,W,4] -> wire (quantised as amav_frames_to_rgb8 does); tiles beyond
+ *   `capacity_tiles` are dropped and header[1] > header[2] tells every receiver.  capacity 0 only counts.
+ *   tile_hint (optional, int32 [F * tiles per frame]): zero = the caller knows the tile is pure background, e.g.
+ *   amav_rasterize_tile_counts (a tile without Gaussians); with a hint the frames are read for the stored tiles only.
+ * amav_frames_unpack_tiles: `num_buffers` gathered wire buffers (rank r at wire_all + r * wire_stride) -> dense uint8
+ *   RGB [num_buffers * F, H, W, 3]; status[0] |= 1 if any buffer was truncated or is not a wire buffer (the caller
+ *   re-packs with more room, as with the rasterizer's instance capacity).  No host synchronisation in either call. */
+/* Per-tile Gaussian list lengths of the last amav_rasterize_forward on this workspace, int32 [F * tiles per frame]
+ * (frame-major, tiles row-major; all ones after an instance-capacity overflow).  Same sizes as the forward call. */
+int amav_rasterize_tile_counts(const void *workspace, int num_frames, int num_gaussians, int height, int width,
+                               int64_t instance_capacity, int32_t *out_counts_dev, void *stream);
+size_t amav_frames_wire_bytes(int num_frames, int height, int width, int64_t capacity_tiles);
+int amav_frames_pack_tiles(int num_frames, int height, int width, const float *rgba_dev, const float *background_host3,
+                           const int32_t *tile_hint_dev, int64_t capacity_tiles, void *wire_dev, size_t wire_bytes,
+                           void *stream);
+int amav_frames_unpack_tiles(int num_buffers, int num_frames, int height, int width, int64_t capacity_tiles,
+                             const void *wire_all_dev, size_t wire_stride, uint8_t *out_rgb8_dev, int32_t *status_dev,
+                             void *stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * SMPL-X forward + linear blend skinning for F frames.
  * Replaces smplx.SMPLX.forward -> smplx.lbs.lbs as called at src/models/renderer.py:261-274 (no transl;

@@ -145,3 +145,64 @@ def test_rgb8_packing_matches_the_reference_quantisation(full_clip):
     want = (rgba[..., :3] * 255).to(torch.uint8)  # src/main2.py:351
     assert torch.equal(got, want)
     assert math.isclose(float(got.float().mean()), float(want.float().mean()))
+
+
+def test_sparse_wire_round_trip_is_lossless(full_clip):
+    """pack -> (gather of two different shards, emulated by concatenation) -> unpack == dense uint8 frames, and a wire
+    that is too small is reported instead of silently dropping tiles."""
+    from audio_motion_avatar_amd import ops
+
+    rgba = raster(full_clip, sel=slice(0, 48), clamp_output=True)["rgba"]
+    a, b = rgba[:24].contiguous(), rgba[24:].contiguous()
+    count_a, _ = ops.frames_wire_count(ops.frames_pack_tiles(a, 0))
+    count_b, _ = ops.frames_wire_count(ops.frames_pack_tiles(b, 0))
+    tiles = 24 * 32 * 32
+    assert 0 < count_a < tiles // 2 and 0 < count_b < tiles // 2  # an avatar clip is mostly background
+    cap = max(count_a, count_b) + 7
+    wa, wb = ops.frames_pack_tiles(a, cap), ops.frames_pack_tiles(b, cap)
+    assert ops.frames_wire_count(wa) == (count_a, cap)
+    assert wa.numel() == ops.frames_wire_bytes(24, H, W, cap) < 24 * H * W * 3 // 2
+    out, status = ops.frames_unpack_tiles(torch.stack([wa, wb]), 2, 24, H, W, cap)
+    assert torch.equal(out, ops.frames_to_rgb8(rgba))
+    assert int(status.item()) == 0
+    # too small: flagged
+    small = max(count_a, count_b) - 5
+    ws_ = torch.stack([ops.frames_pack_tiles(a, small), ops.frames_pack_tiles(b, small)])
+    _, status = ops.frames_unpack_tiles(ws_, 2, 24, H, W, small)
+    assert int(status.item()) == 1
+
+
+def test_sparse_wire_handles_partial_tiles_and_other_backgrounds():
+    from audio_motion_avatar_amd import ops
+
+    g = torch.Generator().manual_seed(2)
+    F_, H_, W_ = 3, 50, 70  # neither a multiple of 16; W not a multiple of 4 -> byte stores
+    for W2 in (W_, 72):
+        rgba = torch.zeros(F_, H_, W2, 4)
+        rgba[..., 0], rgba[..., 1], rgba[..., 2] = 0.25, 0.5, 0.75  # background
+        rgba[1, 10:30, 5:40, :3] = torch.rand(20, 35, 3, generator=g)
+        rgba[2, 45:, 60:, :3] = torch.rand(5, W2 - 60, 3, generator=g)
+        rgba = rgba.cuda().contiguous()
+        bg = (0.25, 0.5, 0.75)
+        count, _ = ops.frames_wire_count(ops.frames_pack_tiles(rgba, 0, bg))
+        assert 0 < count <= 3 * 3 + 1  # the two patches touch a handful of tiles; frame 0 none
+        wire = ops.frames_pack_tiles(rgba, count, bg)
+        out, status = ops.frames_unpack_tiles(wire[None], 1, F_, H_, W2, count)
+        want = (rgba[..., :3].clamp(0, 1) * 255).to(torch.uint8)
+        assert torch.equal(out, want) and int(status.item()) == 0
+
+
+def test_sparse_wire_with_the_rasterizer_tile_hint(full_clip):
+    """The rasterizer's per-tile list lengths as the "may differ from background" hint: a superset of the tiles the
+    pixel test stores, same frames after unpacking, no pass over the fp32 frames for the flags."""
+    from audio_motion_avatar_amd import ops
+
+    out = raster(full_clip, sel=slice(60, 92), clamp_output=True)
+    rgba, hint = out["rgba"], out["workspace"].tile_counts()
+    assert hint.shape == (32 * 32 * 32,) and int((hint > 0).sum()) > 0
+    exact, _ = ops.frames_wire_count(ops.frames_pack_tiles(rgba, 0))
+    hinted, _ = ops.frames_wire_count(ops.frames_pack_tiles(rgba, 0, tile_hint=hint))
+    assert exact <= hinted == int((hint > 0).sum()) <= 1.2 * exact + 8
+    wire = ops.frames_pack_tiles(rgba, hinted, tile_hint=hint)
+    dense, status = ops.frames_unpack_tiles(wire[None], 1, 32, H, W, hinted)
+    assert torch.equal(dense, ops.frames_to_rgb8(rgba)) and int(status.item()) == 0
