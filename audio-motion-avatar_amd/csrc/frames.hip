@@ -211,40 +211,44 @@ __global__ __launch_bounds__(256) void tile_unpack_kernel(int buffers, int tiles
 
 // Row form of the unpack for widths that are multiples of 16 pixels: one thread per 16-byte chunk of an output row, so
 // the stores of a wave are one contiguous kilobyte.  A chunk lies inside one tile row (48 bytes, 16-byte aligned).
-__global__ __launch_bounds__(256) void tile_unpack_rows_kernel(long long chunks, int F, int gx, int T, int H, int W,
-                                                               int cap, const unsigned char *__restrict__ wire,
+__global__ __launch_bounds__(256) void tile_unpack_rows_kernel(int rows, int F, int gx, int T, int H, int W, int cap,
+                                                               const unsigned char *__restrict__ wire,
                                                                size_t wire_stride, uint4 *__restrict__ out,
                                                                int *__restrict__ status) {
-    const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= chunks) return;
-    const int per_row = W * 3 / 16;                 // chunks per pixel row = 3 per tile
-    const int j = (int)(id % per_row);
-    const long long row = id / per_row;             // (buffer * F + frame) * H + y
-    const int y = (int)(row % H);
-    const long long bf = row / H;
-    const int f = (int)(bf % F), b = (int)(bf / F);
-    const int tx = j / 3, part = j - tx * 3;
-    const int tile = f * T + (y >> 4) * gx + tx;
-    const unsigned char *buf = wire + (size_t)b * wire_stride;
-    const int *header = reinterpret_cast<const int *>(buf);
-    const int off = header[kWireHeaderInts + F + tile];
-    if (id % ((long long)per_row * H * F) == 0 && (header[0] != kWireMagic || header[1] > cap)) atomicOr(status, 1);
-    uint4 v;
-    if (off >= 0 && off < cap) {
-        const size_t pay_at = ((size_t)(kWireHeaderInts + F + F * T) * 4 + 15) / 16 * 16;
-        v = *reinterpret_cast<const uint4 *>(buf + pay_at + (size_t)off * kTileBytes + (y & 15) * 48 + part * 16);
-    } else {
-        const unsigned bgw = (unsigned)header[7];
-        const unsigned c[3] = {bgw & 255u, (bgw >> 8) & 255u, (bgw >> 16) & 255u};
-        unsigned w4[4];
+    constexpr int kRows = 4;                         // pixel rows per block
+    const int per_row = W * 3 / 16;                  // chunks per pixel row = 3 per tile
+    const int row0 = blockIdx.x * kRows;             // row = (buffer * F + frame) * H + y
+    for (int c = threadIdx.x; c < per_row * kRows; c += blockDim.x) {
+        const int r = c / per_row, j = c - r * per_row;
+        const int row = row0 + r;
+        if (row >= rows) break;
+        const int bf = row / H, y = row - bf * H;
+        const int b = bf / F, f = bf - b * F;
+        const int tx = j / 3, part = j - tx * 3;
+        const int tile = f * T + (y >> 4) * gx + tx;
+        const unsigned char *buf = wire + (size_t)b * wire_stride;
+        const int *header = reinterpret_cast<const int *>(buf);
+        const int off = header[kWireHeaderInts + F + tile];
+        if (j == 0 && y == 0 && f == 0 && (header[0] != kWireMagic || header[1] > cap)) atomicOr(status, 1);
+        uint4 v;
+        if (off >= 0 && off < cap) {
+            const size_t pay_at = ((size_t)(kWireHeaderInts + F + F * T) * 4 + 15) / 16 * 16;
+            v = *reinterpret_cast<const uint4 *>(buf + pay_at + (size_t)off * kTileBytes + (y & 15) * 48 + part * 16);
+        } else {
+            const unsigned bgw = (unsigned)header[7];
+            const unsigned ch[3] = {bgw & 255u, (bgw >> 8) & 255u, (bgw >> 16) & 255u};
+            unsigned w4[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {  // byte n of the chunk is channel (16 * part + n) % 3
-            const int n0 = 16 * part + 4 * k;
-            w4[k] = c[n0 % 3] | (c[(n0 + 1) % 3] << 8) | (c[(n0 + 2) % 3] << 16) | (c[(n0 + 3) % 3] << 24);
+            for (int k = 0; k < 4; ++k) {  // byte n of the chunk is channel (16 * part + n) % 3
+                const int n0 = 16 * part + 4 * k;
+                w4[k] = ch[n0 % 3] | (ch[(n0 + 1) % 3] << 8) | (ch[(n0 + 2) % 3] << 16) | (ch[(n0 + 3) % 3] << 24);
+            }
+            v = make_uint4(w4[0], w4[1], w4[2], w4[3]);
         }
-        v = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 nv = {v.x, v.y, v.z, v.w};  // streaming store: the frames are not read again on this GPU
+        __builtin_nontemporal_store(nv, reinterpret_cast<u32x4 *>(out) + ((size_t)row * per_row + j));
     }
-    out[id] = v;
 }
 
 static size_t wire_payload_at(int F, int tiles) { return ((size_t)(kWireHeaderInts + F + tiles) * 4 + 15) / 16 * 16; }
@@ -308,9 +312,10 @@ extern "C" int amav_frames_unpack_tiles(int num_buffers, int F, int H, int W, in
                  "amav_frames_unpack_tiles: misaligned buffer");
     const int gx = (W + 15) / 16, T = gx * ((H + 15) / 16), tiles = F * T;
     if (W % 16 == 0 && (reinterpret_cast<uintptr_t>(out_rgb8) & 15) == 0) {
-        const long long chunks = (long long)num_buffers * F * H * (W * 3 / 16);
-        tile_unpack_rows_kernel<<<(unsigned)((chunks + 255) / 256), 256, 0, static_cast<hipStream_t>(stream_)>>>(
-            chunks, F, gx, T, H, W, (int)cap_tiles, static_cast<const unsigned char *>(wire_all), wire_stride,
+        const long long rows = (long long)num_buffers * F * H;
+        AMAV_REQUIRE(rows < 0x7fffffffLL, "amav_frames_unpack_tiles: %lld pixel rows exceed the launch grid", rows);
+        tile_unpack_rows_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, static_cast<hipStream_t>(stream_)>>>(
+            (int)rows, F, gx, T, H, W, (int)cap_tiles, static_cast<const unsigned char *>(wire_all), wire_stride,
             reinterpret_cast<uint4 *>(out_rgb8), status);
         return check_launch("amav_frames_unpack_tiles");
     }
