@@ -23,7 +23,7 @@ def random_scene(seed, N, H, W, F=1, spread=0.35, depth=2.5, log_scale=-3.6, sca
     return dict(xyz=xyz, rot=rot, scale=scale, opacity=opacity, color=color, K=K, E=E, H=H, W=W)
 
 
-def oracle_frames(scene, dtype=np.float32, bg=(1, 1, 1)):
+def oracle_frames(scene, dtype=np.float32, bg=(1, 1, 1), **settings):
     """Run every frame of `scene` through the C oracle (already-activated inputs)."""
     from oracle import camera, rasterizer
 
@@ -34,7 +34,7 @@ def oracle_frames(scene, dtype=np.float32, bg=(1, 1, 1)):
                                                     scene["W"])
         outs.append(rasterizer.rasterize_c(scene["xyz"][f], scene["rot"][f], scene["scale"][f], scene["opacity"][f],
                                            scene["color"][f], view, proj, tx, ty, bg, scene["H"], scene["W"],
-                                           dtype=dtype))
+                                           dtype=dtype, **settings))
     return outs
 
 

@@ -33,8 +33,8 @@ def run_hip(scene, **kw):
     return out
 
 
-def compare(scene, out, tol=TOL):
-    ref = oracle_frames(scene, np.float32)
+def compare(scene, out, tol=TOL, **settings):
+    ref = oracle_frames(scene, np.float32, **settings)
     rgba = out["rgba"].cpu().numpy()
     for f, r in enumerate(ref):
         got_rgb = np.moveaxis(rgba[f, :, :, :3], -1, 0)
@@ -56,6 +56,15 @@ def compare(scene, out, tol=TOL):
 def test_random_scenes(N, H, W, F):
     scene = random_scene(1234 + N, N, H, W, F)
     compare(scene, run_hip(scene))
+
+
+@pytest.mark.parametrize("settings", [dict(antialiasing=True), dict(scale_modifier=0.6),
+                                      dict(antialiasing=True, scale_modifier=1.7)])
+def test_rasterization_settings(settings):
+    """GaussianRasterizationSettings.antialiasing (opacity scaled by sqrt(det / det_lowpass)) and .scale_modifier: the
+    reference passes False / 1.0 (renderer.py:520,529); the op supports the other values like upstream."""
+    scene = random_scene(4321, 1500, 160, 208, 2)
+    compare(scene, run_hip(scene, **settings), **settings)
 
 
 def test_full_size_config():
