@@ -13,6 +13,8 @@
 //                         (normalise rot, sigmoid colour, xyz + offset + transl) and one packed 64-byte record.
 //
 // Same real-number function as the reference; rounding differs only by summation order.
+#include <cstdlib>
+
 #include "amav_common.h"
 
 namespace amav {
@@ -44,11 +46,14 @@ __global__ __launch_bounds__(256) void project_kernel(int C, int RR, const float
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int o = 0; o < 16; ++o) acc[t][o] = 0.0f;
-#pragma unroll kUnroll
-    for (int c = 0; c < C; ++c) {
-        // read-once stream: non-temporal so the slab does not evict the projected planes / weights from L2
-        const f32x4 x = kNT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(src + (size_t)c * S))
-                            : *reinterpret_cast<const f32x4 *>(src + (size_t)c * S);
+    // read-once stream: non-temporal so the slab does not evict the projected planes / weights from L2.  Two register
+    // buffers of kUnroll channels: the loads of the next group are issued before the current group's FMAs, so a wave
+    // always has kUnroll..2*kUnroll kilobytes in flight (a single unrolled loop drains to zero at every trip).
+    auto load = [&](int c) {
+        return kNT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(src + (size_t)c * S))
+                   : *reinterpret_cast<const f32x4 *>(src + (size_t)c * S);
+    };
+    auto fma_channel = [&](int c, const f32x4 &x) {
         const float4 *wc = reinterpret_cast<const float4 *>(w_lds + c * 16);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -62,7 +67,27 @@ __global__ __launch_bounds__(256) void project_kernel(int C, int RR, const float
                 acc[3][g * 4 + e] += wv[e] * x.w;
             }
         }
+    };
+    f32x4 xa[kUnroll], xb[kUnroll];
+    const int groups = C / kUnroll;  // full groups; the tail is handled below
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) xa[u] = load(min(u, C - 1));
+    for (int g0 = 0; g0 < groups; g0 += 2) {
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) xb[u] = load(min((g0 + 1) * kUnroll + u, C - 1));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) fma_channel(g0 * kUnroll + u, xa[u]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (g0 + 1 >= groups) break;
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) xa[u] = load(min((g0 + 2) * kUnroll + u, C - 1));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) fma_channel((g0 + 1) * kUnroll + u, xb[u]);
+        __builtin_amdgcn_sched_barrier(0);
     }
+    for (int c = groups * kUnroll; c < C; ++c) fma_channel(c, load(c));
     float4 *dst = reinterpret_cast<float4 *>(out + (((size_t)f * 3 + plane) * RR + (size_t)q * 4) * 16);
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -261,9 +286,17 @@ extern "C" int amav_triplane_project(int F, int C, int R, const float *tokens, i
     const bool vec = (RR % 4 == 0) && (frame_stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(tokens) & 15) == 0);
     if (vec) {
         const dim3 grid((RR / 4 + 255) / 256, 3, F);
-        // unroll 4/8/16 and plain vs non-temporal loads all measure 207-226 us for 786 MB (3.6-3.9 TB/s read-only)
-        project_kernel<8, true><<<grid, 256, (size_t)C * 16 * sizeof(float), stream>>>(C, RR, tokens, frame_stride, wplane,
-                                                                                       out);
+        // 786 MB slab: 140 us (5.6 TB/s) with the double-buffered loads at 4 channels per buffer (8: 149 us, 2: 145 us); the
+        // single unrolled loop it replaces drained its loads at every trip and stopped at 216 us (3.6 TB/s).
+        // AMAV_PROJECT_UNROLL = 2 / 4 / 8 is a tuning aid.
+        static const int unroll = getenv("AMAV_PROJECT_UNROLL") ? atoi(getenv("AMAV_PROJECT_UNROLL")) : 4;
+        const size_t lds = (size_t)C * 16 * sizeof(float);
+        if (unroll == 8)
+            project_kernel<8, true><<<grid, 256, lds, stream>>>(C, RR, tokens, frame_stride, wplane, out);
+        else if (unroll == 2)
+            project_kernel<2, true><<<grid, 256, lds, stream>>>(C, RR, tokens, frame_stride, wplane, out);
+        else
+            project_kernel<4, true><<<grid, 256, lds, stream>>>(C, RR, tokens, frame_stride, wplane, out);
     } else {
         const dim3 grid((RR + 255) / 256, 3, F);
         project_kernel_scalar<<<grid, 256, 0, stream>>>(C, RR, tokens, frame_stride, wplane, out);
