@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void sample_decode_kernel(int F, int N, int R,
         const float *pp = points + ((size_t)f * N + n) * 3;
         p0 = pp[0], p1 = pp[1], p2 = pp[2];
     }
-    const float u0 = fminf(fmaxf(p0 / radius, -1.0f), 1.0f);
+    const float u0 = fminf(fmaxf(p0 / radius, -1.0f), 1.0f);  // IEEE division, as torch: the taps depend on it
     const float u1 = fminf(fmaxf(p1 / radius, -1.0f), 1.0f);
     const float u2 = fminf(fmaxf(p2 / radius, -1.0f), 1.0f);
     const int RR = R * R;
@@ -225,14 +225,16 @@ __global__ __launch_bounds__(256) void sample_decode_kernel(int F, int N, int R,
         if (transl) tx = transl[f * 3], ty = transl[f * 3 + 1], tz = transl[f * 3 + 2];
         rec = make_float4(p0 + acc.x + tx, p1 + acc.y + ty, p2 + acc.z + tz, acc.w);
     } else if (q == 1) {
-        // F.normalize(dim=-1): v / max(||v||, 1e-12)
-        const float nrm = fmaxf(sqrtf(acc.x * acc.x + acc.y * acc.y + acc.z * acc.z + acc.w * acc.w), 1e-12f);
-        rec = make_float4(acc.x / nrm, acc.y / nrm, acc.z / nrm, acc.w / nrm);
+        // F.normalize(dim=-1): v / max(||v||, 1e-12).  Hardware sqrt / reciprocal (1 ulp): the four lane roles of a
+        // quad run one after the other, so the IEEE division and exp sequences were a third of the kernel's issue slots
+        const float nrm = fmaxf(__fsqrt_rn(acc.x * acc.x + acc.y * acc.y + acc.z * acc.z + acc.w * acc.w), 1e-12f);
+        const float inv = __frcp_rn(nrm);
+        rec = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
     } else if (q == 2) {
         rec = make_float4(acc.x, acc.y, acc.z, 0.0f);
     } else {
-        rec = make_float4(1.0f / (1.0f + expf(-acc.x)), 1.0f / (1.0f + expf(-acc.y)), 1.0f / (1.0f + expf(-acc.z)),
-                          0.0f);
+        rec = make_float4(__frcp_rn(1.0f + __expf(-acc.x)), __frcp_rn(1.0f + __expf(-acc.y)),
+                          __frcp_rn(1.0f + __expf(-acc.z)), 0.0f);
     }
     reinterpret_cast<float4 *>(out)[((size_t)f * N + n) * 4 + q] = rec;
 }
