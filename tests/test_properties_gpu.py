@@ -206,3 +206,39 @@ def test_sparse_wire_with_the_rasterizer_tile_hint(full_clip):
     wire = ops.frames_pack_tiles(rgba, hinted, tile_hint=hint)
     dense, status = ops.frames_unpack_tiles(wire[None], 1, 32, H, W, hinted)
     assert torch.equal(dense, ops.frames_to_rgb8(rgba)) and int(status.item()) == 0
+
+
+def test_render_step_is_hip_graph_capturable(full_clip):
+    """no entry point of the C ABI allocates or synchronises, so one pass of the hot path
+    (LBS + projection on a side stream + fused decode + binning + sort + blend) captures into a HIP graph; the replay
+    reproduces the eager frames bit for bit, also after the inputs change in place."""
+    from audio_motion_avatar_amd import ops
+
+    r, tokens, smpl, cam = (full_clip[k] for k in ("renderer", "tokens", "smpl", "cam"))
+    Fg = 24
+    tok = tokens[0, :Fg].clone()
+    sp = {k: v[:, :Fg].clone() for k, v in smpl.items()}
+    cm = {k: v[:, :Fg].clone() for k, v in cam.items()}
+    ws = [None]
+    with torch.no_grad():
+        eager, _ = r.render_tokens(tok, sp, cm, workspaces=ws)  # sizes the workspace, warms the side streams
+        eager = eager.clone()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                out, _ = r.render_tokens(tok, sp, cm, workspaces=ws, check_overflow=False)
+        torch.cuda.current_stream().wait_stream(side)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, eager)
+        assert not ws[0].status()[1]
+        # new pose in the same buffers -> replay renders the new frames
+        sp["global_orient"].add_(0.3)
+        want, _ = r.render_tokens(tok, sp, cm, workspaces=[None])
+        want = want.clone()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, want) and not torch.equal(want, eager)
