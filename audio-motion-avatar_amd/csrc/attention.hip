@@ -14,6 +14,8 @@
 //     O^T = V^T P^T -- the probabilities never leave the registers;
 //   * K is staged in LDS transposed ([d][key], padded) and V row-major, which makes every operand fetch a
 //     conflict-free 32-lane row read; the next K/V tile is prefetched into registers under the current tile's MFMAs.
+#include <cstdlib>
+
 #include "amav_common.h"
 
 namespace amav {
@@ -29,7 +31,7 @@ constexpr int kLdk = kBN + 1; // padded row of the transposed K tile
 // nsplit > 1: the key range is cut into nsplit slices handled by different workgroups (finer tasks balance the
 // 1576 wave-tasks of the reference shape over 1024 SIMDs); each slice writes its un-normalised O, running max and
 // sum to `part`, and combine_kernel merges them.
-__global__ __launch_bounds__(256) void selfattn_kernel(const float *__restrict__ q, const float *__restrict__ k,
+__global__ __launch_bounds__(256, 3) void selfattn_kernel(const float *__restrict__ q, const float *__restrict__ k,
                                                        const float *__restrict__ v, float *__restrict__ out, int S,
                                                        long long row_stride, long long out_row_stride,
                                                        float scale_log2e, int nsplit, float *__restrict__ part) {
@@ -205,6 +207,8 @@ __global__ __launch_bounds__(256) void combine_kernel(const float *__restrict__ 
 // Key-range split that best balances the (q-tile, head, batch) workgroups over the chip: a CU runs two workgroups
 // at a time (LDS / registers), so the kernel lasts ceil(blocks * s / CUs) slices of 1/s of the key sweep.
 static int choose_split(int B, int S, int H, int num_cus) {
+    static const int forced = getenv("AMAV_ATTN_SPLIT") ? atoi(getenv("AMAV_ATTN_SPLIT")) : 0;  // tuning aid
+    if (forced >= 1 && forced <= 16 && ((S + kBN - 1) / kBN) / forced >= 1) return forced;
     const long long blocks = (long long)((S + kBM - 1) / kBM) * H * B;
     const int ntiles = (S + kBN - 1) / kBN;
     int best = 1;
