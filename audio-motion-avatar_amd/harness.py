@@ -9,6 +9,8 @@ Only the inference I/O of the boundary is reproduced (SURVEY.md section 8b "call
                       caller passes the tokens it produced.
   * `rollout`       : the demo's window chaining -- every window of T_out frames is generated from the last two
                       outputs of the previous one (main2.py:179-203: `triplanes, smplx_tokens = out[:, -2:]`).
+  * `rollout_interleaved`: the demo's even / odd chains over a stride-2 clip, run as one batch of two and zipped
+                      (main2.py:160-311).
   * `rollout_sharded`: the multi-GPU form: each rank rolls and renders its own contiguous block of windows
                       (segment-parallel, SURVEY section 8e option i; `mode="sequential"` = option ii: rank 0 runs the
                       one exact chain and hands out token blocks) and the clip is reassembled by an all-gather of
@@ -85,6 +87,26 @@ class AudioDrivenAvatar(nn.Module):
             images.append(out[0])
             triplanes, smplx_tokens = out[3][:, -2:], out[4][:, -2:]  # chain into the next window
         return {"images": torch.cat(images, dim=1), "triplanes": triplanes, "smplx_tokens": smplx_tokens}
+
+    @torch.no_grad()
+    def rollout_interleaved(self, seeds, audio_features, cam_params, num_windows=None):
+        """The demo's two interleaved chains (main2.py:160-311).  Every dataset item is a stride-2 clip
+        (dataset_speech_vid.py:150), so the demo rolls an "even" chain over frames 0,2,4,... seeded from item 0 and an
+        "odd" chain over frames 1,3,5,... seeded from item 1, and zips the two frame lists (main2.py:301-311).
+
+        seeds = ((triplanes_even, smplx_tokens_even), (triplanes_odd, smplx_tokens_odd)), each [1,2,...];
+        audio_features [1, 2*W*T_out, 768] and cam_params [1, 2*W*T_out, ...] are per output frame of the zipped clip.
+        The chains are independent, so they run as ONE batch of two.  Returns images [2*W*T_out, H, W, 3]."""
+        (tri_e, smpl_e), (tri_o, smpl_o) = seeds
+        T = self.audio_triplane.T_output
+        n = audio_features.shape[1]
+        W = n // (2 * T) if num_windows is None else num_windows
+        if W < 1 or n < 2 * W * T or cam_params["intrinsic"].shape[1] < 2 * W * T:
+            raise ValueError(f"need {2 * W * T} audio tokens and cameras for 2 x {W} windows of {T} frames")
+        unzip = lambda x: torch.cat([x[:, 0:2 * W * T:2], x[:, 1:2 * W * T:2]], dim=0)  # [2, W*T, ...]: even, odd
+        out = self.rollout(torch.cat([tri_e, tri_o]), torch.cat([smpl_e, smpl_o]), unzip(audio_features),
+                           {k: unzip(v) for k, v in cam_params.items()}, num_windows=W)["images"]
+        return torch.stack([out[0], out[1]], dim=1).reshape(2 * W * T, *out.shape[2:])  # e0, o0, e1, o1, ...
 
     @torch.no_grad()
     def rollout_tokens(self, triplanes, smplx_tokens, audio_features, num_windows):
