@@ -153,7 +153,7 @@ class FrameAllGather:
             else:
                 ops.frames_pack_tiles(rgba.view(F, H, W, 4), self.capacity, self.bg, wire=self.local[i],
                                       tile_hint=tile_hint)
-                dist.all_gather_into_tensor(self.gathered[i], self.local[i], group=self.group)
+                dist.all_gather_into_tensor(self.gathered[i].view(-1), self.local[i], group=self.group)
                 ops.frames_unpack_tiles(self.gathered[i], self.world, F, H, W, self.capacity, out=self.full[i],
                                         status=self.status)
         return self.full[i]

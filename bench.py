@@ -273,6 +273,8 @@ def main():
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if os.environ.get("AMAV_BENCH_SINGLE_DEVICE") == "1":  # rehearsal of N > 1 on a one-GPU box (with the gloo backend)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
     dist = None
@@ -282,7 +284,11 @@ def main():
 
         if force_exchange and "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=torch.device(device))
+        backend = os.environ.get("AMAV_BENCH_BACKEND", "nccl")  # "gloo" only to rehearse the rank logic without xGMI
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(device))
+        else:
+            dist.init_process_group(backend)
 
     if args.workload == "full":
         run_full_workload(args, device, world, rank, dist)
@@ -368,6 +374,17 @@ def main():
     total = sum(s[0] for s in status)
     assert not any(s[1] for s in status), "rasterizer workspace overflowed inside the timed region"
     assert gather is None or not gather.overflowed(), "exchange wire buffer overflowed inside the timed region"
+    exchange_ok = None
+    if gather is not None:  # the reassembled clip of the last step: this rank's block must be its own frames
+        full = gather.full[gather.turn ^ 1]
+        mine = full[rank * F:(rank + 1) * F]
+        ok = torch.equal(mine, ops.frames_to_rgb8(out.view(F, H, W, 4)))
+        others = [full[r * F:(r + 1) * F] for r in range(world) if r != rank]
+        ok = ok and all(bool((o != 255).any()) for o in others)  # and the other blocks hold rendered frames
+        t = torch.tensor([int(ok)], device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        exchange_ok = bool(t.item())
+        assert exchange_ok, "the all-gathered clip does not match the frames the ranks rendered"
 
     # blend-kernel time per step = sum over the step's frame groups (one launch each)
     blend_ms = sorted(sum(s.elapsed_ms(e) for s, e in step_events) for step_events in events)
@@ -393,7 +410,7 @@ def main():
                                "no audio net", "frames_per_gpu_per_step": F, "gaussians": N, "image": [H, W],
                    "triplane": [cfg.triplane_feature_dim, cfg.triplane_resolution],
                    "instances_per_step": int(total), "stream_pipelined_frame_groups": len(workspaces),
-                   "exchange": exchange_description(gather)},
+                   "exchange": exchange_description(gather), "exchange_verified": exchange_ok},
         "roofline": {"bound": "hbm", "kernel": "render_kernel (tile blend)", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": pmc_traffic_bytes("render_kernel") if (F, N, H) == (250, 10000, 512) else None,
