@@ -31,6 +31,7 @@ namespace amav {
 namespace raster {
 
 constexpr int kTile = AMAV_TILE;
+constexpr int kRenderWaves = 1;    // waves (= tiles) per blend workgroup
 constexpr int kSortCap = 512;      // keys a wave sorts in its LDS slice (4 KiB); longer lists go to sort_big
 constexpr int kBigLdsCap = 2048;   // keys a sort_big block sorts in LDS (16 KiB); longer lists are sorted in place
 constexpr int kBigBlocks = 1280;
@@ -957,21 +958,22 @@ __device__ __forceinline__ int xcc_id() {
     return v & (kQueues - 1);
 }
 
-// Blend kernel.  One block = up to four non-empty tiles (one per wave) + a share of the background tiles.  Tiles are
-// taken from bucketed lists, LONGEST LISTS FIRST: on this chip a dispatch recycles workgroup slots in dispatch order,
+// Blend kernel.  One workgroup = one wave = one non-empty tile + a share of the background tiles (four tiles per
+// workgroup held every slot until the slowest of the four was done: 4000-4400 of 5120 wave slots busy in mid-kernel
+// against 4700-5000 now).  Tiles are taken from bucketed lists, LONGEST LISTS FIRST: on this chip a dispatch recycles workgroup slots in dispatch order,
 // so a grid that mixes empty and long tiles strands most slots behind the long ones (measured 1.5 of 5 slots per CU
 // busy with one block per tile quad); with neighbours of similar length the hardware dispatcher balances the load.
 // Block b reads queue b % 8: blocks are dealt round-robin over the XCDs, so an XCD's L2 keeps seeing the frames of
 // its own queue (a placement assumption that only affects speed).
 template <bool kInvDepth>
-__global__ __launch_bounds__(256) void render_kernel(Params p) {
-    __shared__ WaveLds lds4[4];
+__global__ __launch_bounds__(64 * kRenderWaves) void render_kernel(Params p) {
+    __shared__ WaveLds lds4[kRenderWaves];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const Status *st = p.buf.status;
-    const int gw = blockIdx.x * 4 + wave;
+    const int gw = blockIdx.x * kRenderWaves + wave;
     if (!st->overflow) {
         const int q = blockIdx.x % kQueues;
-        const int i = (blockIdx.x / kQueues) * 4 + wave;  // position in queue q's concatenated buckets
+        const int i = (blockIdx.x / kQueues) * kRenderWaves + wave;  // position in queue q's concatenated buckets
         int acc = 0, b = 0;
         for (; b < kBuckets; ++b) {
             const int c = st->qcount[q][b];
@@ -985,7 +987,7 @@ __global__ __launch_bounds__(256) void render_kernel(Params p) {
     }
     // background tiles (every tile when the instance regions overflowed: the caller must retry)
     const int nempty = st->nempty;
-    const int nw = gridDim.x * 4, per = (nempty + nw - 1) / nw;
+    const int nw = gridDim.x * kRenderWaves, per = (nempty + nw - 1) / nw;
     for (int k = gw * per; k < min(nempty, (gw + 1) * per); ++k) fill_tile<kInvDepth>(p, p.buf.empty_list[k], lane);
 }
 
@@ -1071,13 +1073,13 @@ extern "C" int amav_rasterize_forward(const amav_raster_args *a, void *stream_) 
         bin_kernel<false><<<F, 1024, bin_lds, stream>>>(p);
     sort_big_kernel<<<kBigBlocks, 256, 0, stream>>>(p);
     // worst-case grid (every tile non-empty in one queue); must be a multiple of kQueues
-    const long long per_queue = ((long long)p.qcap + 3) / 4;
+    const long long per_queue = ((long long)p.qcap + kRenderWaves - 1) / kRenderWaves;
     const unsigned blocks = (unsigned)(per_queue * kQueues);
     if (a->profile_start_event) (void)hipEventRecord(static_cast<hipEvent_t>(a->profile_start_event), stream);
     if (a->out_inv_depth)
-        render_kernel<true><<<blocks, 256, 0, stream>>>(p);
+        render_kernel<true><<<blocks, 64 * kRenderWaves, 0, stream>>>(p);
     else
-        render_kernel<false><<<blocks, 256, 0, stream>>>(p);
+        render_kernel<false><<<blocks, 64 * kRenderWaves, 0, stream>>>(p);
     if (a->profile_stop_event) (void)hipEventRecord(static_cast<hipEvent_t>(a->profile_stop_event), stream);
     return check_launch("amav_rasterize_forward");
 }
