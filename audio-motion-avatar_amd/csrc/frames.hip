@@ -209,45 +209,43 @@ __global__ __launch_bounds__(256) void tile_unpack_kernel(int buffers, int tiles
     }
 }
 
-// Row form of the unpack for widths that are multiples of 16 pixels: one thread per 16-byte chunk of an output row, so
-// the stores of a wave are one contiguous kilobyte.  A chunk lies inside one tile row (48 bytes, 16-byte aligned).
-__global__ __launch_bounds__(256) void tile_unpack_rows_kernel(int rows, int F, int gx, int T, int H, int W, int cap,
+// Row form of the unpack for widths that are multiples of 16 pixels.  grid = (tile rows, frames, buffers), block =
+// (128 chunk columns, 2 row parities): a thread owns 16-byte chunk columns j (three per tile: a chunk lies inside
+// one tile row of 48 bytes) and writes them for every second pixel row of the band, so a wave's stores are contiguous
+// runs of a pixel row, the tile slot is looked up once per column, and no thread divides by a run-time value.
+__global__ __launch_bounds__(256) void tile_unpack_rows_kernel(int F, int gx, int T, int H, int W, int cap,
                                                                const unsigned char *__restrict__ wire,
-                                                               size_t wire_stride, uint4 *__restrict__ out,
+                                                               size_t wire_stride, unsigned char *__restrict__ out,
                                                                int *__restrict__ status) {
-    constexpr int kRows = 4;                         // pixel rows per block
-    const int per_row = W * 3 / 16;                  // chunks per pixel row = 3 per tile
-    const int row0 = blockIdx.x * kRows;             // row = (buffer * F + frame) * H + y
-    for (int c = threadIdx.x; c < per_row * kRows; c += blockDim.x) {
-        const int r = c / per_row, j = c - r * per_row;
-        const int row = row0 + r;
-        if (row >= rows) break;
-        const int bf = row / H, y = row - bf * H;
-        const int b = bf / F, f = bf - b * F;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const int ty = blockIdx.x, f = blockIdx.y, b = blockIdx.z;
+    const int per_row = W * 3 / 16;
+    const unsigned char *buf = wire + (size_t)b * wire_stride;
+    const int *header = reinterpret_cast<const int *>(buf);
+    const int *offsets = header + kWireHeaderInts + F + f * T + ty * gx;
+    const unsigned char *payload = buf + ((size_t)(kWireHeaderInts + F + F * T) * 4 + 15) / 16 * 16;
+    if (ty == 0 && f == 0 && threadIdx.x == 0 && threadIdx.y == 0 && (header[0] != kWireMagic || header[1] > cap))
+        atomicOr(status, 1);
+    const unsigned bgw = (unsigned)header[7];
+    const unsigned ch[3] = {bgw & 255u, (bgw >> 8) & 255u, (bgw >> 16) & 255u};
+    const int y_end = min(16, H - ty * 16);
+    unsigned char *band = out + (((size_t)b * F + f) * H + (size_t)ty * 16) * W * 3;
+    for (int j = threadIdx.x; j < per_row; j += blockDim.x) {
         const int tx = j / 3, part = j - tx * 3;
-        const int tile = f * T + (y >> 4) * gx + tx;
-        const unsigned char *buf = wire + (size_t)b * wire_stride;
-        const int *header = reinterpret_cast<const int *>(buf);
-        const int off = header[kWireHeaderInts + F + tile];
-        if (j == 0 && y == 0 && f == 0 && (header[0] != kWireMagic || header[1] > cap)) atomicOr(status, 1);
-        uint4 v;
-        if (off >= 0 && off < cap) {
-            const size_t pay_at = ((size_t)(kWireHeaderInts + F + F * T) * 4 + 15) / 16 * 16;
-            v = *reinterpret_cast<const uint4 *>(buf + pay_at + (size_t)off * kTileBytes + (y & 15) * 48 + part * 16);
-        } else {
-            const unsigned bgw = (unsigned)header[7];
-            const unsigned ch[3] = {bgw & 255u, (bgw >> 8) & 255u, (bgw >> 16) & 255u};
-            unsigned w4[4];
+        const int off = offsets[tx];
+        const bool stored = off >= 0 && off < cap;
+        u32x4 bgv;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {  // byte n of the chunk is channel (16 * part + n) % 3
-                const int n0 = 16 * part + 4 * k;
-                w4[k] = ch[n0 % 3] | (ch[(n0 + 1) % 3] << 8) | (ch[(n0 + 2) % 3] << 16) | (ch[(n0 + 3) % 3] << 24);
-            }
-            v = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+        for (int k = 0; k < 4; ++k) {  // byte n of the chunk is channel (16 * part + n) % 3
+            const int n0 = 16 * part + 4 * k;
+            bgv[k] = ch[n0 % 3] | (ch[(n0 + 1) % 3] << 8) | (ch[(n0 + 2) % 3] << 16) | (ch[(n0 + 3) % 3] << 24);
         }
-        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-        u32x4 nv = {v.x, v.y, v.z, v.w};  // streaming store: the frames are not read again on this GPU
-        __builtin_nontemporal_store(nv, reinterpret_cast<u32x4 *>(out) + ((size_t)row * per_row + j));
+        const unsigned char *src = payload + (size_t)(stored ? off : 0) * kTileBytes + part * 16;
+        for (int r = threadIdx.y; r < y_end; r += blockDim.y) {
+            const u32x4 v = stored ? *reinterpret_cast<const u32x4 *>(src + r * 48) : bgv;
+            // streaming store: the frames are not read again on this GPU
+            __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(band + (size_t)r * W * 3) + j);
+        }
     }
 }
 
@@ -311,12 +309,10 @@ extern "C" int amav_frames_unpack_tiles(int num_buffers, int F, int H, int W, in
     AMAV_REQUIRE((reinterpret_cast<uintptr_t>(wire_all) & 15) == 0 && (reinterpret_cast<uintptr_t>(out_rgb8) & 3) == 0,
                  "amav_frames_unpack_tiles: misaligned buffer");
     const int gx = (W + 15) / 16, T = gx * ((H + 15) / 16), tiles = F * T;
-    if (W % 16 == 0 && (reinterpret_cast<uintptr_t>(out_rgb8) & 15) == 0) {
-        const long long rows = (long long)num_buffers * F * H;
-        AMAV_REQUIRE(rows < 0x7fffffffLL, "amav_frames_unpack_tiles: %lld pixel rows exceed the launch grid", rows);
-        tile_unpack_rows_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, static_cast<hipStream_t>(stream_)>>>(
-            (int)rows, F, gx, T, H, W, (int)cap_tiles, static_cast<const unsigned char *>(wire_all), wire_stride,
-            reinterpret_cast<uint4 *>(out_rgb8), status);
+    if (W % 16 == 0 && (reinterpret_cast<uintptr_t>(out_rgb8) & 15) == 0 && F <= 65535 && num_buffers <= 65535) {
+        const dim3 grid((unsigned)(T / gx), (unsigned)F, (unsigned)num_buffers), block(128, 2);
+        tile_unpack_rows_kernel<<<grid, block, 0, static_cast<hipStream_t>(stream_)>>>(
+            F, gx, T, H, W, (int)cap_tiles, static_cast<const unsigned char *>(wire_all), wire_stride, out_rgb8, status);
         return check_launch("amav_frames_unpack_tiles");
     }
     const long long total = (long long)num_buffers * tiles;

@@ -65,9 +65,11 @@ struct Buffers {
     Status *status;
 };
 
-static inline size_t queue_capacity(int F, int T) { return (size_t)((F + kQueues - 1) / kQueues) * T; }
+// a queue holds, of every frame, one band of tile rows (bin_kernel): at most ceil(gy / kQueues) rows of gx tiles
+static inline size_t queue_capacity(int F, int gx, int gy) { return (size_t)F * ((gy + kQueues - 1) / kQueues) * gx; }
 
-static Buffers carve(void *ws, int F, int N, int T, long long cap, size_t *bytes) {
+static Buffers carve(void *ws, int F, int N, int gx, int gy, long long cap, size_t *bytes) {
+    const int T = gx * gy;
     Carver c(ws);
     Buffers b;
     b.status = c.take<Status>(1);
@@ -77,7 +79,7 @@ static Buffers carve(void *ws, int F, int N, int T, long long cap, size_t *bytes
     b.keys = c.take<unsigned long long>((size_t)cap);
     b.sorted = c.take<unsigned>((size_t)cap);
     b.big_list = c.take<int>((size_t)F * T);
-    b.queue = c.take<int>((size_t)kQueues * kBuckets * queue_capacity(F, T));
+    b.queue = c.take<int>((size_t)kQueues * kBuckets * queue_capacity(F, gx, gy));
     b.empty_list = c.take<int>((size_t)F * T);
     if (bytes) *bytes = c.total();
     return b;
@@ -284,13 +286,13 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int *lds_wave, int *t
     return wave_prefix + incl - v;
 }
 
-// grid = F blocks of 1024 threads; dynamic LDS = (2*T + 16 + 3*(kBuckets+1)) ints: counts[T], cursor[T], scratch, classes
+// grid = F blocks of 1024 threads; dynamic LDS = (2*T + 16 + 3*8*(kBuckets+1)) ints: counts[T], cursor[T], scratch, classes
 template <bool kPacked>
 __global__ __launch_bounds__(1024) void bin_kernel(Params p) {
     extern __shared__ int bin_lds[];
     int *counts = bin_lds;
     int *cursor = bin_lds + p.T;
-    int *scratch = bin_lds + 2 * p.T + 3 * (kBuckets + 1);
+    int *scratch = bin_lds + 2 * p.T + 3 * kQueues * (kBuckets + 1);
     const int f = blockIdx.x;
     for (int t = threadIdx.x; t < p.T; t += blockDim.x) counts[t] = 0;
     __syncthreads();
@@ -343,30 +345,34 @@ __global__ __launch_bounds__(1024) void bin_kernel(Params p) {
         }
     }
     const bool fits = (long long)total <= p.cap_per_frame;
-    // work items of the blend kernel: non-empty tiles into this frame's queue, bucketed by list length; empty tiles
-    // into the fill list.  Two LDS-counted passes: count per class, reserve ranges with one global atomic each, emit.
-    int *cls = cursor + p.T;  // [kBuckets + 1] counts, then bases, then emit cursors (class kBuckets = empty)
-    constexpr int kCls = kBuckets + 1;
-    if (threadIdx.x < 3 * kCls) cls[threadIdx.x] = 0;
+    // work items of the blend kernel: non-empty tiles into the work queues, bucketed by list length; empty tiles into
+    // the fill list.  Queue of a tile = (band of its tile row + frame) % 8: every queue (= XCD, see render_kernel)
+    // gets one eighth of EVERY frame, rotating, so the queues carry equal work whatever the frames look like, and a
+    // queue's Gaussian records stay spatially local.
+    // Two LDS-counted passes: count per (queue, class), reserve ranges with one global atomic each, emit.
+    constexpr int kCls = kBuckets + 1, kQK = kQueues * kCls;  // class kBuckets = empty
+    int *cls = cursor + p.T;  // [kQK] counts, then bases, then emit cursors
+    if (threadIdx.x < 3 * kQK) cls[threadIdx.x] = 0;
     __syncthreads();
+    auto queue_of = [&](int t) { return (min(kQueues - 1, (t / p.gx) * kQueues / p.gy) + f) % kQueues; };
     for (int k = 0; k < per; ++k)
         if (t0 + k < p.T) {
             const int c = fits ? counts[t0 + k] : 0;
-            atomicAdd(&cls[c == 0 ? kBuckets : bucket_of(c)], 1);
+            atomicAdd(&cls[queue_of(t0 + k) * kCls + (c == 0 ? kBuckets : bucket_of(c))], 1);
         }
     __syncthreads();
-    const int qi = f % kQueues;
-    if (threadIdx.x < kBuckets) {
-        if (cls[threadIdx.x]) cls[kCls + threadIdx.x] = atomicAdd(&p.buf.status->qcount[qi][threadIdx.x], cls[threadIdx.x]);
-    } else if (threadIdx.x == kBuckets) {
-        cls[kCls + kBuckets] = atomicAdd(&p.buf.status->nempty, cls[kBuckets]);
+    if (threadIdx.x < kQK && cls[threadIdx.x]) {
+        const int q = threadIdx.x / kCls, kind = threadIdx.x - q * kCls;
+        cls[kQK + threadIdx.x] = kind == kBuckets ? atomicAdd(&p.buf.status->nempty, cls[threadIdx.x])
+                                                  : atomicAdd(&p.buf.status->qcount[q][kind], cls[threadIdx.x]);
     }
     __syncthreads();
     for (int k = 0; k < per; ++k)
         if (t0 + k < p.T) {
             const int c = fits ? counts[t0 + k] : 0;
             const int kind = c == 0 ? kBuckets : bucket_of(c);
-            const int pos = cls[kCls + kind] + atomicAdd(&cls[2 * kCls + kind], 1);
+            const int qi = queue_of(t0 + k), slot = qi * kCls + kind;
+            const int pos = cls[kQK + slot] + atomicAdd(&cls[2 * kQK + slot], 1);
             if (kind == kBuckets)
                 p.buf.empty_list[pos] = f * p.T + t0 + k;
             else
@@ -1001,7 +1007,7 @@ extern "C" size_t amav_rasterize_workspace_bytes(int F, int N, int H, int W, int
     if (F <= 0 || N <= 0 || H <= 0 || W <= 0 || capacity < 0) return 0;
     const int gx = (W + kTile - 1) / kTile, gy = (H + kTile - 1) / kTile;
     size_t bytes = 0;
-    carve(nullptr, F, N, gx * gy, capacity / F * F, &bytes);
+    carve(nullptr, F, N, gx, gy, capacity / F * F, &bytes);
     return bytes;
 }
 
@@ -1022,14 +1028,14 @@ extern "C" int amav_rasterize_forward(const amav_raster_args *a, void *stream_) 
     AMAV_REQUIRE(gx < 65536 && gy < 65536, "amav_rasterize_forward: image too large");
     const int T = gx * gy;
     AMAV_REQUIRE((long long)F * T < (1ll << 31), "amav_rasterize_forward: F * tiles overflows int32");
-    const size_t bin_lds = ((size_t)2 * T + 16 + 3 * (kBuckets + 1)) * sizeof(int);
+    const size_t bin_lds = ((size_t)2 * T + 16 + 3 * kQueues * (kBuckets + 1)) * sizeof(int);
     AMAV_REQUIRE(bin_lds <= 160 * 1024, "amav_rasterize_forward: %d tiles need %zu B of LDS in the binning block (max 160 KiB)",
                  T, bin_lds);
     const long long cap_per_frame = a->instance_capacity / F;
     AMAV_REQUIRE(cap_per_frame < (1ll << 31), "amav_rasterize_forward: per-frame instance capacity overflows int32");
     size_t need = 0;
     Params p;
-    p.buf = carve(a->workspace, F, N, T, cap_per_frame * F, &need);
+    p.buf = carve(a->workspace, F, N, gx, gy, cap_per_frame * F, &need);
     if (a->workspace_bytes < need)
         return fail(AMAV_ERR_WORKSPACE, "amav_rasterize_forward: workspace %zu < required %zu", a->workspace_bytes, need);
     p.F = F, p.N = N, p.H = a->height, p.W = a->width, p.gx = gx, p.gy = gy, p.T = T;
@@ -1043,7 +1049,7 @@ extern "C" int amav_rasterize_forward(const amav_raster_args *a, void *stream_) 
     p.antialiasing = a->antialiasing, p.clamp_output = a->clamp_output;
     p.out_rgba = a->out_rgba, p.out_inv_depth = a->out_inv_depth, p.out_radii = a->out_radii;
     p.cap_per_frame = cap_per_frame;
-    p.qcap = (int)queue_capacity(F, T);
+    p.qcap = (int)queue_capacity(F, gx, gy);
     p.stamps = static_cast<unsigned long long *>(a->debug_stamps);
 
     hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -1103,7 +1109,7 @@ extern "C" int amav_rasterize_tile_counts(const void *workspace, int F, int N, i
     AMAV_REQUIRE(F > 0 && N > 0 && H > 0 && W > 0 && capacity >= 0, "amav_rasterize_tile_counts: bad sizes");
     const int gx = (W + kTile - 1) / kTile, gy = (H + kTile - 1) / kTile, T = gx * gy;
     size_t bytes = 0;
-    const Buffers b = carve(const_cast<void *>(workspace), F, N, T, capacity / F * F, &bytes);
+    const Buffers b = carve(const_cast<void *>(workspace), F, N, gx, gy, capacity / F * F, &bytes);
     tile_counts_kernel<<<(unsigned)(((long long)F * T + 255) / 256), 256, 0, static_cast<hipStream_t>(stream_)>>>(
         F, T, b.status, b.tile_off, out_counts);
     return check_launch("amav_rasterize_tile_counts");

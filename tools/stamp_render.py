@@ -51,3 +51,18 @@ for q in np.linspace(0, ts.max(), 21)[1:]:
     i = np.searchsorted(ts, q) - 1
     hv = ((sn[:, 0] - t0) * US <= q) & ((sn[:, 4] - t0) * US >= q)
     print(f"  t={q:7.1f} us  waves in flight {int(conc[i]):5d}  (nonempty {int(hv.sum())})")
+# who is still running at the end?
+end = (sn[:, 4] - t0) * US
+start = (sn[:, 0] - t0) * US
+late = end > 0.9 * ts.max()
+print(f"tiles finishing in the last 10 % of the kernel: {late.sum()}")
+for lo, hi in ((1, 32), (32, 64), (64, 128), (128, 256), (256, 512), (512, 10**9)):
+    m = late & (sn[:, 5] >= lo) & (sn[:, 5] < hi)
+    if m.any():
+        print(f"  n in [{lo},{hi}): {m.sum():5d} tiles  start {start[m].min():6.1f}..{start[m].max():6.1f} us  "
+              f"duration mean {(end[m] - start[m]).mean():6.1f} max {(end[m] - start[m]).max():6.1f} us")
+# dispatch order: when does each length class start?
+for lo, hi in ((1, 32), (32, 64), (64, 128), (128, 256), (256, 512), (512, 10**9)):
+    m = (sn[:, 5] >= lo) & (sn[:, 5] < hi)
+    if m.any():
+        print(f"  class [{lo},{hi}): starts {np.percentile(start[m], 1):6.1f} .. {np.percentile(start[m], 99):6.1f} us (p1..p99)")
