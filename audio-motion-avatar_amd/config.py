@@ -41,6 +41,7 @@ class RendererConfig:
     device: str = "cuda"
     # deterministic-inference additions (SURVEY.md "Hard parts"): the reference re-draws the vertex subset with
     # torch.randperm on every forward (renderer.py:287); here it is drawn once from this seed.
+    num_gaussians: Optional[int] = None  # None: the reference's SUBDEVIDE_VERTS[subdivide_steps]
     subset_seed: int = 42
     subset_order: str = "random"      # "spatial": the same subset, stored along a Z-order curve of the rest pose
     body_seed: int = 42               # seed of the synthetic body used when smplx_model_path is absent

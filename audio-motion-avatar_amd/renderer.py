@@ -58,7 +58,9 @@ class Renderer(nn.Module):
             raise NotImplementedError("the PTv3 point refiner (renderer.py:34-47,143-151) is a SURVEY 8(f) next-row; "
                                       "set no_point_refiner=True (an untrained refiner outputs zero offsets anyway)")
         self.smplx_model = self.init_smplx_model()
-        self.num_verts = SUBDEVIDE_VERTS[self.cfg.subdivide_steps]
+        # the reference's table (renderer.py:14-18,25); `num_gaussians` overrides it (BASELINE's 50 000-Gaussian stress
+        # config has no entry there)
+        self.num_verts = int(getattr(self.cfg, "num_gaussians", None) or SUBDEVIDE_VERTS[self.cfg.subdivide_steps])
         self.init_smplx_subdivider(subdivide_steps=self.cfg.subdivide_steps)
         self.smpl_decoder = smpl_decoder if cfg.predict_smplx_params else None
         if getattr(cfg, "upsample_triplane", False):
@@ -99,6 +101,8 @@ class Renderer(nn.Module):
         levels = max(1, subdivide_steps)
         table = build_subdivision_table(self.smplx_model.faces, self.smplx_model.num_verts, levels)
         g = torch.Generator().manual_seed(int(getattr(self.cfg, "subset_seed", 42)))
+        if self.num_verts > table.shape[0]:
+            raise ValueError(f"{self.num_verts} Gaussians requested, the mesh subdivided {levels}x has {table.shape[0]} vertices")
         idx = torch.randperm(table.shape[0], generator=g)[: self.num_verts]
         if getattr(self.cfg, "subset_order", "random") == "spatial":
             idx = idx[_morton_order(self.smplx_model.v_template.detach().cpu(), torch.as_tensor(table)[idx])]

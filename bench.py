@@ -59,10 +59,11 @@ def parse():
                     help="frame groups pipelined on separate HIP streams (1 is fastest; 2 costs 17 percent more time, 4 costs 56 percent)")
     ap.add_argument("--wire", choices=["sparse", "dense"], default="sparse",
                     help="N > 1 exchange format: non-background 16x16 tiles of the uint8 frames (lossless) or all of them")
-    ap.add_argument("--workload", choices=["render", "full"], default="render",
+    ap.add_argument("--workload", choices=["render", "full", "stress"], default="render",
                     help="render = BASELINE configs[1] (static decode + LBS + rasterize, the metric's config); "
                          "full = configs[2]: synthetic audio tokens -> AudioTriplaneNet (autoregressive) -> SMPL-X "
-                         "decoder -> LBS -> decode -> rasterize")
+                         "decoder -> LBS -> decode -> rasterize; stress = configs[4] per GPU: triplane 128^2 x 512 "
+                         "channels, 50 000 Gaussians, 1024x1024, decode + LBS + rasterize (32 frames per step)")
     return ap.parse_args()
 
 
@@ -72,11 +73,14 @@ def build_renderer(args, device, with_decoder=False):
     from audio_motion_avatar_amd.smplx_decoder import SMPLXDecoder
     from audio_motion_avatar_amd.synthetic import init_random_heads
 
-    steps = {10000: 0, 30000: 1}.get(args.gaussians)
-    if steps is None:
+    stress = args.workload == "stress"
+    steps = {10000: 0, 30000: 1, 50000: 2}.get(args.gaussians)
+    if steps is None or (args.gaussians == 50000 and not stress):
         raise SystemExit("--gaussians must be 10000 or 30000 (the reference's SUBDEVIDE_VERTS table)")
     cfg = RendererConfig(image_size=(args.image, args.image), subdivide_steps=steps,
                          predict_smplx_params=with_decoder, device=device)
+    if stress:  # BASELINE configs[4]
+        cfg.triplane_resolution, cfg.triplane_feature_dim, cfg.num_gaussians = 128, 512, args.gaussians
     dec = SMPLXDecoder(cfg).to(device) if with_decoder else None
     return init_random_heads(Renderer(cfg, smpl_decoder=dec).eval()), cfg
 
@@ -290,6 +294,11 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    if args.workload == "stress":
+        args.gaussians, args.image = 50000, 1024
+        if args.frames == 250:
+            args.frames = 32  # 3.2 GB of triplane tokens per step
+        args.cpu_frames = min(args.cpu_frames, 1)
     if args.workload == "full":
         run_full_workload(args, device, world, rank, dist)
         if dist is not None:
@@ -406,8 +415,10 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: 512x512, 10k Gaussians, static triplane decode + LBS + rasterize, "
-                               "no audio net", "frames_per_gpu_per_step": F, "gaussians": N, "image": [H, W],
+        "config": {"workload": ("BASELINE configs[4] (per GPU): triplane 128^2 x 512 ch, 50k Gaussians, 1024x1024, static "
+                                "triplane decode + LBS + rasterize, no audio net" if args.workload == "stress" else
+                                "BASELINE configs[1]: 512x512, 10k Gaussians, static triplane decode + LBS + rasterize, "
+                                "no audio net"), "frames_per_gpu_per_step": F, "gaussians": N, "image": [H, W],
                    "triplane": [cfg.triplane_feature_dim, cfg.triplane_resolution],
                    "instances_per_step": int(total), "stream_pipelined_frame_groups": len(workspaces),
                    "exchange": exchange_description(gather), "exchange_verified": exchange_ok},
@@ -416,6 +427,22 @@ def main():
                      "traffic": pmc_traffic_bytes("render_kernel") if (F, N, H) == (250, 10000, 512) else None,
                      "avg_launch_ms": blend_avg_ms, "algorithmic_bytes_per_launch": blend_bytes},
     }
+    if args.workload == "stress":  # the stage that dominates this configuration is the slab projection (HBM stream)
+        w_plane, _ = renderer._head_weights()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        for _ in range(3):
+            ops.triplane_project(tokens[0], w_plane, cfg.triplane_resolution)
+        ev[0].record()
+        for _ in range(10):
+            ops.triplane_project(tokens[0], w_plane, cfg.triplane_resolution)
+        ev[1].record()
+        torch.cuda.synchronize()
+        ms = ev[0].elapsed_time(ev[1]) / 10
+        slab = F * 3 * cfg.triplane_feature_dim * cfg.triplane_resolution ** 2 * 4
+        result["roofline_project"] = {"bound": "hbm", "kernel": "project_kernel (triplane slab stream)", "achieved":
+                                      slab / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": slab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": ms,
+                                      "algorithmic_bytes_per_launch": slab, "note": "timed stand-alone in this process"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base, parity = cpu_baseline_and_parity(renderer, cfg, tokens, smpl, cam, stages, args.cpu_frames)
         result["cpu_baseline"] = base
