@@ -97,12 +97,26 @@ __global__ __launch_bounds__(256, 3) void selfattn_kernel(const float *__restric
         f32x16 S0, S1;
 #pragma unroll
         for (int t = 0; t < 16; ++t) S0[t] = 0.f, S1[t] = 0.f;
+        // the K operands of step s + 2 are read from LDS before the MFMAs of step s issue: read just in time, every
+        // MFMA pair waited a full LDS round trip (ds_read; s_waitcnt 0; mfma; mfma), which the other waves of the SIMD
+        // only partly covered
+        float ka[2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            ka[u][0] = Kt[(2 * u + hh) * kLdk + c];
+            ka[u][1] = Kt[(2 * u + hh) * kLdk + 32 + c];
+        }
 #pragma unroll
         for (int s = 0; s < 32; ++s) {
-            const float a0 = Kt[(2 * s + hh) * kLdk + c];
-            const float a1 = Kt[(2 * s + hh) * kLdk + 32 + c];
+            const float a0 = ka[s & 1][0], a1 = ka[s & 1][1];
+            if (s + 2 < 32) {
+                ka[s & 1][0] = Kt[(2 * (s + 2) + hh) * kLdk + c];
+                ka[s & 1][1] = Kt[(2 * (s + 2) + hh) * kLdk + 32 + c];
+            }
+            __builtin_amdgcn_sched_barrier(0);
             S0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, Qr[s], S0, 0, 0, 0);
             S1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, Qr[s], S1, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);  // pin the order: read of step s + 2, then this step's two MFMAs
         }
         // accumulator register t of key half kb holds key  kt*64 + kb*32 + (t&3) + 8*(t>>2) + 4*hh
         if ((kt + 1) * kBN > S) {
@@ -123,30 +137,31 @@ __global__ __launch_bounds__(256, 3) void selfattn_kernel(const float *__restric
         const float m_new = fmaxf(m_run, mx);
         const float corr = __builtin_amdgcn_exp2f(m_run - m_new);
         m_run = m_new;
-        float psum = 0.f;
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            S0[t] = __builtin_amdgcn_exp2f(S0[t] - m_new);
-            S1[t] = __builtin_amdgcn_exp2f(S1[t] - m_new);
-            psum += S0[t] + S1[t];
-        }
-        l_run = l_run * corr + psum;  // per-half partial sum; the halves are added once at the end
 #pragma unroll
         for (int t = 0; t < 16; ++t) O0[t] *= corr, O1[t] *= corr;
 
-        // ---- O^T += V^T P^T: accumulator register t is the B operand of k-step {key r, key r + 4}
+        // ---- O^T += V^T P^T: score register t of key half kb is the B operand of k-step {key r, key r + 4}, with
+        // r = 32 kb + (t & 3) + 8 (t >> 2) + 4 hh.  Same pinned pipeline as above: the V operands of step u + 2 are
+        // read and the probability of step u + 1 is exponentiated before the two MFMAs of step u issue, so the LDS
+        // round trip and the quarter-rate exp run under the matrix pipe.
+        auto vrow = [&](int u) { return ((u >> 4) * 32 + (u & 3) + 8 * ((u & 15) >> 2) + 4 * hh) * kD + c; };
+        auto score = [&](int u) { return (u < 16 ? S0[u] : S1[u - 16]) - m_new; };
+        float va[3][2];
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const int r = (t & 3) + 8 * (t >> 2) + 4 * hh;
-            O0 = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[r * kD + c], S0[t], O0, 0, 0, 0);
-            O1 = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[r * kD + 32 + c], S0[t], O1, 0, 0, 0);
-        }
+        for (int u = 0; u < 2; ++u) va[u][0] = Vs[vrow(u)], va[u][1] = Vs[vrow(u) + 32];
+        float p_cur = __builtin_amdgcn_exp2f(score(0)), psum = 0.f;
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const int r = 32 + (t & 3) + 8 * (t >> 2) + 4 * hh;
-            O0 = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[r * kD + c], S1[t], O0, 0, 0, 0);
-            O1 = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[r * kD + 32 + c], S1[t], O1, 0, 0, 0);
+        for (int u = 0; u < 32; ++u) {
+            const float v0 = va[u % 3][0], v1 = va[u % 3][1], pu = p_cur;
+            if (u + 2 < 32) va[(u + 2) % 3][0] = Vs[vrow(u + 2)], va[(u + 2) % 3][1] = Vs[vrow(u + 2) + 32];
+            if (u + 1 < 32) p_cur = __builtin_amdgcn_exp2f(score(u + 1));
+            psum += pu;
+            __builtin_amdgcn_sched_barrier(0);
+            O0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, pu, O0, 0, 0, 0);
+            O1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, pu, O1, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        l_run = l_run * corr + psum;  // per-half partial sum; the halves are added once at the end
         __syncthreads();  // every wave is done with this tile before it is overwritten
     }
 
