@@ -209,11 +209,13 @@ __global__ __launch_bounds__(256) void tile_unpack_kernel(int buffers, int tiles
     }
 }
 
-// Row form of the unpack for widths that are multiples of 16 pixels.  grid = (tile rows, frames, buffers), block =
-// (128 chunk columns, 2 row parities): a thread owns 16-byte chunk columns j (three per tile: a chunk lies inside
-// one tile row of 48 bytes) and writes them for every second pixel row of the band, so a wave's stores are contiguous
-// runs of a pixel row, the tile slot is looked up once per column, and no thread divides by a run-time value.
+// Band form of the unpack for widths that are multiples of 16 pixels.  grid = (tile rows, frames, buffers): a block
+// owns one band of 16 pixel rows of one frame, which is one contiguous run of the dense output, and walks it linearly
+// in 16-byte chunks (256 threads x 16 B per trip), so the stores are as linear as a fill.  A chunk lies inside one
+// tile row (48 bytes, 16-byte aligned); row and column of a chunk come from a multiply-shift by the host's reciprocal
+// of the chunks per row, so no thread divides by a run-time value.
 __global__ __launch_bounds__(256) void tile_unpack_rows_kernel(int F, int gx, int T, int H, int W, int cap,
+                                                               unsigned per_row_magic,
                                                                const unsigned char *__restrict__ wire,
                                                                size_t wire_stride, unsigned char *__restrict__ out,
                                                                int *__restrict__ status) {
@@ -224,28 +226,31 @@ __global__ __launch_bounds__(256) void tile_unpack_rows_kernel(int F, int gx, in
     const int *header = reinterpret_cast<const int *>(buf);
     const int *offsets = header + kWireHeaderInts + F + f * T + ty * gx;
     const unsigned char *payload = buf + ((size_t)(kWireHeaderInts + F + F * T) * 4 + 15) / 16 * 16;
-    if (ty == 0 && f == 0 && threadIdx.x == 0 && threadIdx.y == 0 && (header[0] != kWireMagic || header[1] > cap))
-        atomicOr(status, 1);
+    if (ty == 0 && f == 0 && threadIdx.x == 0 && (header[0] != kWireMagic || header[1] > cap)) atomicOr(status, 1);
     const unsigned bgw = (unsigned)header[7];
     const unsigned ch[3] = {bgw & 255u, (bgw >> 8) & 255u, (bgw >> 16) & 255u};
-    const int y_end = min(16, H - ty * 16);
-    unsigned char *band = out + (((size_t)b * F + f) * H + (size_t)ty * 16) * W * 3;
-    for (int j = threadIdx.x; j < per_row; j += blockDim.x) {
-        const int tx = j / 3, part = j - tx * 3;
-        const int off = offsets[tx];
-        const bool stored = off >= 0 && off < cap;
-        u32x4 bgv;
+    u32x4 bgv[3];  // background chunk by position inside the tile row: byte n of chunk `part` is channel (16 part + n) % 3
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {  // byte n of the chunk is channel (16 * part + n) % 3
+    for (int part = 0; part < 3; ++part)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
             const int n0 = 16 * part + 4 * k;
-            bgv[k] = ch[n0 % 3] | (ch[(n0 + 1) % 3] << 8) | (ch[(n0 + 2) % 3] << 16) | (ch[(n0 + 3) % 3] << 24);
+            bgv[part][k] = ch[n0 % 3] | (ch[(n0 + 1) % 3] << 8) | (ch[(n0 + 2) % 3] << 16) | (ch[(n0 + 3) % 3] << 24);
         }
-        const unsigned char *src = payload + (size_t)(stored ? off : 0) * kTileBytes + part * 16;
-        for (int r = threadIdx.y; r < y_end; r += blockDim.y) {
-            const u32x4 v = stored ? *reinterpret_cast<const u32x4 *>(src + r * 48) : bgv;
-            // streaming store: the frames are not read again on this GPU
-            __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(band + (size_t)r * W * 3) + j);
-        }
+    const int rows = min(16, H - ty * 16);
+    u32x4 *band = reinterpret_cast<u32x4 *>(out + (((size_t)b * F + f) * H + (size_t)ty * 16) * W * 3);
+    // the band's tile slots once, into LDS: a load in front of every store would put a memory round trip in each trip
+    __shared__ int slot[1024];
+    for (int tx = threadIdx.x; tx < gx; tx += blockDim.x) slot[tx] = offsets[tx];
+    __syncthreads();
+    for (int cidx = threadIdx.x; cidx < rows * per_row; cidx += blockDim.x) {
+        const int r = (int)__umulhi((unsigned)cidx, per_row_magic), j = cidx - r * per_row;
+        const int tx = j / 3, part = j - tx * 3;
+        const int off = slot[tx];
+        u32x4 v = part == 0 ? bgv[0] : (part == 1 ? bgv[1] : bgv[2]);
+        if (off >= 0 && off < cap)
+            v = *reinterpret_cast<const u32x4 *>(payload + (size_t)off * kTileBytes + r * 48 + part * 16);
+        __builtin_nontemporal_store(v, band + cidx);  // streaming store: the frames are not read again on this GPU
     }
 }
 
@@ -310,9 +315,13 @@ extern "C" int amav_frames_unpack_tiles(int num_buffers, int F, int H, int W, in
                  "amav_frames_unpack_tiles: misaligned buffer");
     const int gx = (W + 15) / 16, T = gx * ((H + 15) / 16), tiles = F * T;
     if (W % 16 == 0 && (reinterpret_cast<uintptr_t>(out_rgb8) & 15) == 0 && F <= 65535 && num_buffers <= 65535) {
-        const dim3 grid((unsigned)(T / gx), (unsigned)F, (unsigned)num_buffers), block(128, 2);
-        tile_unpack_rows_kernel<<<grid, block, 0, static_cast<hipStream_t>(stream_)>>>(
-            F, gx, T, H, W, (int)cap_tiles, static_cast<const unsigned char *>(wire_all), wire_stride, out_rgb8, status);
+        const dim3 grid((unsigned)(T / gx), (unsigned)F, (unsigned)num_buffers);
+        const unsigned per_row = (unsigned)(W * 3 / 16);
+        const unsigned magic = (unsigned)((0x100000000ULL + per_row - 1) / per_row);  // exact for dividends < 2^16
+        AMAV_REQUIRE(16u * per_row < 65536u && gx <= 1024, "amav_frames_unpack_tiles: width %d too large for the band kernel", W);
+        tile_unpack_rows_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream_)>>>(
+            F, gx, T, H, W, (int)cap_tiles, magic, static_cast<const unsigned char *>(wire_all), wire_stride, out_rgb8,
+            status);
         return check_launch("amav_frames_unpack_tiles");
     }
     const long long total = (long long)num_buffers * tiles;
