@@ -1,5 +1,6 @@
 // Frame post-processing for the exchange step: fp32 RGBA -> uint8 RGB, the on-wire format of the all-gather.
 // Quantisation is the reference's own (src/main2.py:351: `(frame * 255).astype(np.uint8)`, i.e. truncation).
+#include <algorithm>
 #include <cmath>
 
 #include "amav_common.h"
@@ -220,13 +221,12 @@ __global__ __launch_bounds__(256) void tile_unpack_rows_kernel(int F, int gx, in
                                                                size_t wire_stride, unsigned char *__restrict__ out,
                                                                int *__restrict__ status) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    const int ty = blockIdx.x, f = blockIdx.y, b = blockIdx.z;
+    const int f = blockIdx.y, b = blockIdx.z;
     const int per_row = W * 3 / 16;
     const unsigned char *buf = wire + (size_t)b * wire_stride;
     const int *header = reinterpret_cast<const int *>(buf);
-    const int *offsets = header + kWireHeaderInts + F + f * T + ty * gx;
     const unsigned char *payload = buf + ((size_t)(kWireHeaderInts + F + F * T) * 4 + 15) / 16 * 16;
-    if (ty == 0 && f == 0 && threadIdx.x == 0 && (header[0] != kWireMagic || header[1] > cap)) atomicOr(status, 1);
+    if (blockIdx.x == 0 && f == 0 && threadIdx.x == 0 && (header[0] != kWireMagic || header[1] > cap)) atomicOr(status, 1);
     const unsigned bgw = (unsigned)header[7];
     const unsigned ch[3] = {bgw & 255u, (bgw >> 8) & 255u, (bgw >> 16) & 255u};
     u32x4 bgv[3];  // background chunk by position inside the tile row: byte n of chunk `part` is channel (16 part + n) % 3
@@ -237,20 +237,25 @@ __global__ __launch_bounds__(256) void tile_unpack_rows_kernel(int F, int gx, in
             const int n0 = 16 * part + 4 * k;
             bgv[part][k] = ch[n0 % 3] | (ch[(n0 + 1) % 3] << 8) | (ch[(n0 + 2) % 3] << 16) | (ch[(n0 + 3) % 3] << 24);
         }
-    const int rows = min(16, H - ty * 16);
-    u32x4 *band = reinterpret_cast<u32x4 *>(out + (((size_t)b * F + f) * H + (size_t)ty * 16) * W * 3);
-    // the band's tile slots once, into LDS: a load in front of every store would put a memory round trip in each trip
     __shared__ int slot[1024];
-    for (int tx = threadIdx.x; tx < gx; tx += blockDim.x) slot[tx] = offsets[tx];
-    __syncthreads();
-    for (int cidx = threadIdx.x; cidx < rows * per_row; cidx += blockDim.x) {
-        const int r = (int)__umulhi((unsigned)cidx, per_row_magic), j = cidx - r * per_row;
-        const int tx = j / 3, part = j - tx * 3;
-        const int off = slot[tx];
-        u32x4 v = part == 0 ? bgv[0] : (part == 1 ? bgv[1] : bgv[2]);
-        if (off >= 0 && off < cap)
-            v = *reinterpret_cast<const u32x4 *>(payload + (size_t)off * kTileBytes + r * 48 + part * 16);
-        __builtin_nontemporal_store(v, band + cidx);  // streaming store: the frames are not read again on this GPU
+    const int gy = T / gx;
+    for (int ty = blockIdx.x; ty < gy; ty += gridDim.x) {  // a block walks several bands: fewer, longer workgroups
+        const int *offsets = header + kWireHeaderInts + F + f * T + ty * gx;
+        const int rows = min(16, H - ty * 16);
+        u32x4 *band = reinterpret_cast<u32x4 *>(out + (((size_t)b * F + f) * H + (size_t)ty * 16) * W * 3);
+        __syncthreads();  // the previous band's slots have been consumed
+        // the band's tile slots once, into LDS: a load in front of every store would put a memory round trip in each trip
+        for (int tx = threadIdx.x; tx < gx; tx += blockDim.x) slot[tx] = offsets[tx];
+        __syncthreads();
+        for (int cidx = threadIdx.x; cidx < rows * per_row; cidx += blockDim.x) {
+            const int r = (int)__umulhi((unsigned)cidx, per_row_magic), j = cidx - r * per_row;
+            const int tx = j / 3, part = j - tx * 3;
+            const int off = slot[tx];
+            u32x4 v = part == 0 ? bgv[0] : (part == 1 ? bgv[1] : bgv[2]);
+            if (off >= 0 && off < cap)
+                v = *reinterpret_cast<const u32x4 *>(payload + (size_t)off * kTileBytes + r * 48 + part * 16);
+            __builtin_nontemporal_store(v, band + cidx);  // streaming store: the frames are not read again on this GPU
+        }
     }
 }
 
@@ -315,7 +320,7 @@ extern "C" int amav_frames_unpack_tiles(int num_buffers, int F, int H, int W, in
                  "amav_frames_unpack_tiles: misaligned buffer");
     const int gx = (W + 15) / 16, T = gx * ((H + 15) / 16), tiles = F * T;
     if (W % 16 == 0 && (reinterpret_cast<uintptr_t>(out_rgb8) & 15) == 0 && F <= 65535 && num_buffers <= 65535) {
-        const dim3 grid((unsigned)(T / gx), (unsigned)F, (unsigned)num_buffers);
+        const dim3 grid((unsigned)std::min(T / gx, 4), (unsigned)F, (unsigned)num_buffers);
         const unsigned per_row = (unsigned)(W * 3 / 16);
         const unsigned magic = (unsigned)((0x100000000ULL + per_row - 1) / per_row);  // exact for dividends < 2^16
         AMAV_REQUIRE(16u * per_row < 65536u && gx <= 1024, "amav_frames_unpack_tiles: width %d too large for the band kernel", W);
