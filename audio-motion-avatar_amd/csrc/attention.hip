@@ -286,3 +286,35 @@ extern "C" int amav_selfattn_forward(int B, int S, int H, int D, const float *q,
     }
     return check_launch("amav_selfattn_forward");
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// GEGLU gate of the feed-forward (src/models/transformers.py:484-508: hidden, gate = proj(x).chunk(2); hidden *
+// gelu(gate), exact-erf GELU): one pass over the projection's [rows, 2 * inner] output instead of torch's two
+// elementwise kernels (gelu, then mul), i.e. 1.5 instead of 2.5 tensor sweeps.
+namespace amav {
+namespace attn {
+__global__ __launch_bounds__(256) void geglu_kernel(long long quads, int inner4, const float4 *__restrict__ in,
+                                                    long long in_row4, float4 *__restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= quads) return;
+    const long long row = i / inner4;
+    const int col = (int)(i - row * inner4);
+    const float4 h = in[row * in_row4 + col], g = in[row * in_row4 + inner4 + col];
+    auto gelu = [](float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); };
+    out[i] = make_float4(h.x * gelu(g.x), h.y * gelu(g.y), h.z * gelu(g.z), h.w * gelu(g.w));
+}
+}  // namespace attn
+}  // namespace amav
+
+extern "C" int amav_geglu(int64_t rows, int inner, const float *proj, int64_t proj_row_stride, float *out, void *stream) {
+    AMAV_REQUIRE(rows > 0 && inner > 0 && inner % 4 == 0, "amav_geglu: bad sizes rows=%lld inner=%d", (long long)rows, inner);
+    AMAV_REQUIRE(proj && out, "amav_geglu: NULL pointer");
+    AMAV_REQUIRE(proj_row_stride >= 2LL * inner && proj_row_stride % 4 == 0, "amav_geglu: bad row stride");
+    AMAV_REQUIRE(((reinterpret_cast<uintptr_t>(proj) | reinterpret_cast<uintptr_t>(out)) & 15) == 0,
+                 "amav_geglu: buffers must be 16-byte aligned");
+    const long long quads = rows * (inner / 4);
+    amav::attn::geglu_kernel<<<(unsigned)((quads + 255) / 256), 256, 0, static_cast<hipStream_t>(stream)>>>(
+        quads, inner / 4, reinterpret_cast<const float4 *>(proj), proj_row_stride / 4, reinterpret_cast<float4 *>(out));
+    return check_launch("amav_geglu");
+}

@@ -457,3 +457,15 @@ def selfattn(q, k, v, heads, scale=None):
                                            out.data_ptr(), HD, float(scale if scale is not None else D ** -0.5),
                                            ws.data_ptr(), nbytes, _stream()), "amav_selfattn_forward")
     return out
+
+
+def geglu(proj):
+    """proj [..., 2*inner] (contiguous, fp32) -> [..., inner] = proj[..., :inner] * gelu(proj[..., inner:]) (exact erf)."""
+    proj = _need(proj, "proj")
+    if not proj.is_contiguous() or proj.shape[-1] % 8:
+        raise AmavError("geglu: need a contiguous [..., 2*inner] tensor with inner a multiple of 4")
+    inner = proj.shape[-1] // 2
+    out = torch.empty(*proj.shape[:-1], inner, device=proj.device)
+    check(_lib.lib().amav_geglu(proj.numel() // proj.shape[-1], inner, proj.data_ptr(), proj.shape[-1], out.data_ptr(),
+                                _stream()), "amav_geglu")
+    return out

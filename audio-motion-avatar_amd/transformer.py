@@ -69,7 +69,10 @@ class GEGLU(nn.Module):
         self.proj = nn.Linear(dim_in, dim_out * 2)
 
     def forward(self, hidden_states):
-        hidden_states, gate = self.proj(hidden_states).chunk(2, dim=-1)
+        proj = self.proj(hidden_states)
+        if proj.is_cuda and proj.dtype == torch.float32 and not torch.is_grad_enabled() and proj.shape[-1] % 8 == 0:
+            return ops.geglu(proj.contiguous())  # one fused pass (csrc/attention.hip)
+        hidden_states, gate = proj.chunk(2, dim=-1)  # CPU construction / autograd
         return hidden_states * F.gelu(gate)
 
 

@@ -234,6 +234,10 @@ int amav_selfattn_forward(int batch, int seq_len, int heads, int head_dim, const
                           const float *v_dev, int64_t row_stride, float *out_dev, int64_t out_row_stride,
                           float scale, void *workspace, size_t workspace_bytes, void *stream);
 
+/* GEGLU gate of the transformer feed-forward (src/models/transformers.py:484-508, exact-erf GELU):
+ * proj [rows, 2*inner] (row stride in floats) -> out [rows, inner] = proj[:, :inner] * gelu(proj[:, inner:]). */
+int amav_geglu(int64_t rows, int inner, const float *proj_dev, int64_t proj_row_stride, float *out_dev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
