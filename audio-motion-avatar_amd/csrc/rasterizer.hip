@@ -11,18 +11,21 @@
 //                  the memory side on MI355X (the eight XCD L2s are not coherent; measured 0.43 ms per 8.4 M adds);
 //                  LDS atomics do not.  Frames own fixed instance regions, so there is no cross-frame scan and no
 //                  host round trip (upstream syncs to read the instance count).
-//   sort_big       persistent blocks sort the tile lists longer than 512 in LDS (<= 2 K keys) or in place.
-//   render_kernel  ONE WAVEFRONT PER TILE: loads its keys, sorts them in its LDS slice (rank sort <= 256 keys,
-//                  normalised bitonic <= 512; keys are unique, so the order equals upstream's stable radix sort by
-//                  (tile, depth)), then blends 4 pixels per lane -- one in each 8x8 quadrant of the tile.  Gaussians
+//   sort_big       persistent blocks sort the tile lists longer than 512 keys: an exact bucket sort in LDS (<= 2 K
+//                  keys), a bitonic network for clustered depths or longer lists.
+//   render_kernel  ONE WAVEFRONT PER TILE (and per workgroup): loads its keys and sorts them in its LDS slice -- rank
+//                  sort up to 64 keys, an exact depth-bucket sort up to 512 (comparison sorts when the depths are
+//                  too clustered); keys are unique, so the order equals upstream's stable radix sort by
+//                  (tile, depth) -- then blends 4 pixels per lane, one in each 8x8 quadrant of the tile.  Gaussians
 //                  are staged 64 at a time through LDS; the staging lane tests the Gaussian's exact alpha >= 1/255
 //                  bounding box against the four quadrants, drops Gaussians that cannot touch the tile (ballot +
 //                  mbcnt compaction) and records a 4-bit quadrant mask, so the wave only evaluates quadrants the
 //                  Gaussian can reach (wave-uniform branches; skipped evaluations are ones the reference would
-//                  reject with alpha < 1/255, so the output is unchanged).  Early-out by __all(); the state of a
+//                  reject with alpha < 1/255, so the output is unchanged).  Early-out by __any(); the state of a
 //                  finished pixel is the sign of its transmittance.  Output is pixel-interleaved RGBA, so every
-//                  store instruction writes eight full 128-byte lines.  Block ids are remapped so that one XCD's
-//                  L2 sees whole frames.
+//                  store instruction writes eight full 128-byte lines.  Tiles reach the waves through eight work
+//                  queues (one per XCD: tile-row bands, rotating with the frame) bucketed by list length and
+//                  dispatched longest first.
 #include <cstdlib>
 
 #include "amav_common.h"
