@@ -6,13 +6,14 @@
 //   joint_chain_kernel  one 64-lane block per frame, one lane per joint: Rodrigues (angle = ||r + 1e-8||), joint
 //                       locations from the pre-regressed tables, the kinematic chain level by level in LDS, the
 //                       rest-pose-removed 3x4 transforms A_j, and the frame's blend feature column
-//                       [betas; expression; (R_1..R_54 - I)] written TRANSPOSED ([k][frame]) so the skin kernel can
-//                       fetch 16 frames of one feature with a single scalar load.
-//   skin_kernel         one thread per vertex and FT frames: the [F, 506] x [506, 3V] blend product is done as
-//                       register-tiled FMAs whose frame operand is wave-uniform (SGPR); the 63.6 MB blend table is
-//                       stored as component planes (coalesced rows) and the frame groups of a vertex chunk share an
-//                       XCD, so a chunk is fetched from HBM once; the group's feature slice sits in LDS; then
-//                       T_v = sum_j w_vj A_j and the 3x4 transform.  Nothing but the vertices is written.
+//                       [betas; expression; (R_1..R_54 - I)] written TRANSPOSED ([k][frame]): a feature row is the
+//                       A-operand row of the MFMA kernel and one LDS slice of the FMA kernel.
+//   skin_mfma_kernel    (F > 16) the [F, 506] x [506, 3V] blend product on v_mfma_f32_32x32x2_f32: a block = 128
+//                       frames x 32 vertices, the tile-major blend table streamed once through LDS, then
+//                       T_v = sum_j w_vj A_j and the 3x4 transform in the accumulator layout.
+//   skin_kernel         (F <= 16) one thread per vertex and FT frames: the same product as register-tiled FMAs with
+//                       the group's feature slice in LDS; the frame groups of a vertex chunk share an XCD, so a
+//                       chunk of the 63.6 MB table is fetched from HBM once.  Nothing but the vertices is written.
 //   gather_kernel       baked subdivision table -> the N sampled points.
 #include <cstdlib>
 
