@@ -1,5 +1,6 @@
-// Frame post-processing for the exchange step: fp32 RGBA -> uint8 RGB, the on-wire format of the all-gather.
-// Quantisation is the reference's own (src/main2.py:351: `(frame * 255).astype(np.uint8)`, i.e. truncation).
+// Frame post-processing for the exchange step: fp32 RGBA -> uint8 RGB (dense, or as the tile-sparse wire format of
+// the all-gather below) and back.  Quantisation is the reference's own (src/main2.py:351:
+// `(frame * 255).astype(np.uint8)`, i.e. truncation).
 #include <algorithm>
 #include <cmath>
 
