@@ -150,6 +150,11 @@ __device__ __forceinline__ float quad_bcast(float v) {  // value of lane K of th
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), K * 0x55, 0xf, 0xf, true));
 }
 
+template <int K>
+__device__ __forceinline__ int quad_bcast_i(int v) {
+    return __builtin_amdgcn_mov_dpp(v, K * 0x55, 0xf, 0xf, true);
+}
+
 template <bool kIndexed>
 __global__ __launch_bounds__(256) void sample_decode_kernel(int F, int N, int R, int V,
                                                             const float *__restrict__ proj,
@@ -187,17 +192,14 @@ __global__ __launch_bounds__(256) void sample_decode_kernel(int F, int N, int R,
     const float u2 = fminf(fmaxf(p2 / radius, -1.0f), 1.0f);
     const int RR = R * R;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    // branch-free taps: an out-of-range texel (zero padding) is read at a clamped address with weight 0, so the twelve
-    // 16-byte loads are issued back to back and their latencies overlap
-    float4 tv[12];
-    float tw[12];
-#pragma unroll
-    for (int plane = 0; plane < 3; ++plane) {
-        // plane 0 <- (x, y), plane 1 <- (x, z), plane 2 <- (y, z); grid x indexes W, grid y indexes H
-        const float gx = plane == 2 ? u1 : u0;
-        const float gy = plane == 0 ? u1 : u2;
-        const Taps t = make_taps(gx, gy, R);
-        const float4 *pl = reinterpret_cast<const float4 *>(proj + (((size_t)f * 3 + plane) * RR) * 16) + q;
+    // The four lanes of a point need the same twelve taps.  Lane q < 3 works out plane q's four (texel, weight)
+    // pairs -- branch-free: an out-of-range texel (zero padding) is a clamped address with weight 0 -- and the quad
+    // trades them by DPP; then every lane issues its twelve 16-byte loads back to back.
+    // plane 0 <- (x, y), plane 1 <- (x, z), plane 2 <- (y, z); grid x indexes W, grid y indexes H
+    int my_off[4];
+    float my_w[4];
+    {
+        const Taps t = make_taps(q == 2 ? u1 : u0, q == 0 ? u1 : u2, R);
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
@@ -205,12 +207,22 @@ __global__ __launch_bounds__(256) void sample_decode_kernel(int F, int N, int R,
                 const int ix = t.ix0 + dx, iy = t.iy0 + dy;
                 const bool in = ix >= 0 && ix < R && iy >= 0 && iy < R;
                 const int cx = min(max(ix, 0), R - 1), cy = min(max(iy, 0), R - 1);
-                tw[plane * 4 + dy * 2 + dx] = in ? (dx ? t.wx1 : t.wx0) * (dy ? t.wy1 : t.wy0) : 0.0f;
-                tv[plane * 4 + dy * 2 + dx] = pl[(size_t)(cy * R + cx) * 4];
+                my_w[dy * 2 + dx] = in ? (dx ? t.wx1 : t.wx0) * (dy ? t.wy1 : t.wy0) : 0.0f;
+                my_off[dy * 2 + dx] = (cy * R + cx) * 4;  // in float4 units
             }
     }
+    float4 tv[12];
+    float tw[12];
+    const float4 *pl0 = reinterpret_cast<const float4 *>(proj + ((size_t)f * 3 * RR) * 16) + q;
 #pragma unroll
-    for (int k = 0; k < 12; ++k) {  // same order as before: plane, then dy, then dx
+    for (int k = 0; k < 4; ++k) {
+        tw[k] = quad_bcast<0>(my_w[k]), tw[4 + k] = quad_bcast<1>(my_w[k]), tw[8 + k] = quad_bcast<2>(my_w[k]);
+        tv[k] = pl0[quad_bcast_i<0>(my_off[k])];
+        tv[4 + k] = pl0[(size_t)RR * 4 + quad_bcast_i<1>(my_off[k])];
+        tv[8 + k] = pl0[(size_t)RR * 8 + quad_bcast_i<2>(my_off[k])];
+    }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {  // plane, then dy, then dx
         const float w = tw[k];
         const float4 v = tv[k];
         acc.x += w * v.x, acc.y += w * v.y, acc.z += w * v.z, acc.w += w * v.w;
