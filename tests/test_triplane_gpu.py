@@ -50,6 +50,34 @@ def test_fused_decode_matches_grid_sample_plus_heads(F, N, C, R):
     assert torch.count_nonzero(rec[..., 11]) == 0 and torch.count_nonzero(rec[..., 15]) == 0
 
 
+@pytest.mark.parametrize("F,N,C,R", [(2, 5000, 64, 32), (1, 333, 16, 8)])
+def test_fused_decode_does_not_depend_on_point_order(F, N, C, R):
+    """A point's record depends on nothing but that point: the same points stored along a space-filling curve
+    (RendererConfig.subset_order = "spatial", where the lanes of a wave share texels) or in random order give the same
+    records bit for bit, and match the oracle to the usual tolerance."""
+    from audio_motion_avatar_amd import ops
+    from oracle import triplane as orc
+
+    tokens, points, transl, params = make_case(99 + N, F, N, C, R)
+    q = ((points.clamp(-1.4, 1.4) + 1.4) / 2.8 * 1023).long()
+    code = torch.zeros(F, N, dtype=torch.long)
+    for bit in range(10):
+        for axis in range(3):
+            code |= ((q[..., axis] >> bit) & 1) << (3 * bit + axis)
+    order = torch.argsort(code, dim=1)
+    sorted_pts = torch.gather(points, 1, order[..., None].expand(-1, -1, 3)).contiguous()
+    heads = {n: (params[f"gaussian_decoder.{n}.weight"], params[f"gaussian_decoder.{n}.bias"])
+             for n in ("xyz_layer", "rotation_layer", "scaling_layer", "opacity_layer", "shs_layer")}
+    w_plane, w_point = ops.pack_head_weights(heads, C, "cuda")
+    proj = ops.triplane_project(tokens.cuda(), w_plane, R)
+    rec_sorted = ops.triplane_sample_decode(proj, sorted_pts.cuda(), transl.cuda(), 1.4, w_point).cpu()
+    rec_random = ops.triplane_sample_decode(proj, points.cuda(), transl.cuda(), 1.4, w_point).cpu()
+    assert torch.equal(rec_sorted, torch.gather(rec_random, 1, order[..., None].expand(-1, -1, 16)))
+    ref = orc.decode_gaussians(params, orc.tokens_to_planes(tokens[None], R), sorted_pts, transl, 1.4)
+    assert (rec_sorted[..., 0:3] - ref["xyz"]).abs().max() <= 2e-5
+    assert (rec_sorted[..., 12:15] - ref["color"]).abs().max() <= 2e-5
+
+
 @pytest.mark.parametrize("F,N,C,R", [(2, 300, 16, 8), (1, 500, 256, 32)])
 def test_sample_features_matches_grid_sample(F, N, C, R):
     from audio_motion_avatar_amd import ops

@@ -13,7 +13,8 @@ from audio_motion_avatar_amd.renderer import Renderer  # noqa: E402
 from audio_motion_avatar_amd.synthetic import init_random_heads, make_render_inputs  # noqa: E402
 
 F = 250
-cfg = RendererConfig(image_size=(512, 512), subdivide_steps=0, predict_smplx_params=False, device="cuda")
+cfg = RendererConfig(image_size=(512, 512), subdivide_steps=0, predict_smplx_params=False, device="cuda",
+                     subset_order=os.environ.get("AMAV_SUBSET_ORDER", RendererConfig.subset_order))
 r = init_random_heads(Renderer(cfg).eval())
 tokens, smpl, cam = make_render_inputs(F, cfg, seed=42)
 w_plane, w_point = r._head_weights()
