@@ -8,7 +8,11 @@ resident in HBM before the timed region.  `value` = frames rendered by all ranks
 
 With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU) every rank renders its own 250-frame
 shard (weak scaling) and the rendered sequence is reassembled on every rank by an RCCL all-gather of the uint8 RGB
-frames, issued on a side stream so that it overlaps the next step's rendering.
+frames -- by default of their non-background 16x16 tiles only (lossless, --wire sparse), unpacked to dense frames on
+every rank -- issued on a side stream so that it overlaps the next step's rendering; after the timed region every rank
+checks that its block of the reassembled clip equals the frames it rendered (`config.exchange_verified`).
+Other workloads: --workload full (BASELINE configs[2]/[3]: the autoregressive audio net in front), --workload stress
+(configs[4] per GPU).  stdout carries exactly the one JSON line (RCCL's banner and everything else go to stderr).
 
 Extra objects on the JSON line: `roofline` (the blend kernel, timed live with HIP events around the kernel on its
 own stream), `cpu_baseline` (the CPU oracle = a port, timed on this box's host cores on a bounded sample of the
