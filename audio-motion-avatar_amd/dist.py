@@ -78,7 +78,7 @@ class FrameAllGather:
     wire="sparse" (default): only the 16x16 tiles that differ from the background travel (ops.frames_pack_tiles), and
     every rank unpacks the gathered buffers back into dense uint8 frames -- lossless, ~1/5 of the bytes for an avatar
     clip.  The per-rank tile capacity is fixed by calibrate() (a synchronising call, made once before the timed
-    region: max stored tiles over the ranks + 25 %); a later step that needs more sets `overflowed()`, exactly like
+    region: max stored tiles over the ranks + 10 %); a later step that needs more sets `overflowed()`, exactly like
     the rasterizer's instance capacity.  wire="dense": plain uint8 RGB frames (ops.frames_to_rgb8).
     """
 
@@ -102,7 +102,7 @@ class FrameAllGather:
             self.status = torch.zeros(1, dtype=torch.int32, device=device)
 
     # ---- sparse wire -------------------------------------------------------------------------------------------------
-    def calibrate(self, rgba: torch.Tensor, headroom=1.25, tile_hint=None):
+    def calibrate(self, rgba: torch.Tensor, headroom=1.1, tile_hint=None):
         """Size the per-rank wire buffers from one rendered shard (host sync + a MAX all-reduce: call it in warm-up).
         Pass the same kind of `tile_hint` the steps will pass to submit(): a hint stores a superset of the tiles."""
         from . import ops
