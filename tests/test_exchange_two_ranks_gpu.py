@@ -1,0 +1,72 @@
+"""The N > 1 exchange end to end on the GPU box: two processes (gloo over localhost, both on cuda:0 -- RCCL needs one
+GPU per rank) render different shards, pack them with the HIP kernels, all-gather the wire buffers and unpack; every
+rank must end up with both shards' frames, for the sparse and the dense wire format.  What this cannot cover is RCCL /
+xGMI itself (the driver's multi-GPU run does)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from audio_motion_avatar_amd import ops
+        from audio_motion_avatar_amd.config import RendererConfig
+        from audio_motion_avatar_amd.dist import FrameAllGather
+        from audio_motion_avatar_amd.renderer import Renderer
+        from audio_motion_avatar_amd.synthetic import init_random_heads, make_render_inputs
+
+        F, H, W = 6, 128, 160
+        cfg = RendererConfig(image_size=(H, W), subdivide_steps=0, predict_smplx_params=False, device="cuda")
+        r = init_random_heads(Renderer(cfg).eval())
+        shards = []
+        with torch.no_grad():
+            for rk in range(world):  # every rank renders every shard, so it knows what the gather must deliver
+                tokens, smpl, cam = make_render_inputs(F, cfg, seed=100 + rk, device="cuda")
+                ws = [None]
+                rgba, _ = r.render_tokens(tokens[0], smpl, cam, workspaces=ws)
+                shards.append((rgba.clone(), ws[0].tile_counts().clone()))
+        want = torch.cat([ops.frames_to_rgb8(s[0]) for s in shards])
+        ok = {}
+        for wire in ("sparse", "dense"):
+            gather = FrameAllGather(F, H, W, world, "cuda", wire=wire)
+            mine, hint = shards[rank]
+            if wire == "sparse":
+                gather.calibrate(mine, tile_hint=hint)
+            for _ in range(3):  # both buffers of the double buffering, and a reuse
+                full = gather.submit(mine, tile_hint=hint if wire == "sparse" else None)
+                gather.wait()
+                torch.cuda.synchronize()
+                ok[wire] = bool(torch.equal(full, want)) and not gather.overflowed() and ok.get(wire, True)
+        flags = [None] * world
+        dist.all_gather_object(flags, ok)
+        if rank == 0:
+            out.put(flags)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_exchange_their_shards():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        flags = q.get(timeout=400)
+    finally:
+        for p in procs:
+            p.join(timeout=400)
+    assert all(p.exitcode == 0 for p in procs)
+    assert flags == [{"sparse": True, "dense": True}] * 2
