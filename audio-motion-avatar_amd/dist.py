@@ -39,8 +39,13 @@ def all_gather_frames(local_frames: torch.Tensor, group=None) -> torch.Tensor:
 
 
 def send_frames(block: torch.Tensor, dst: int, group=None):
-    """Non-blocking point-to-point send of a contiguous block of per-frame tensors (tokens) to its owner."""
-    return dist.isend(block.contiguous(), dst=dst, group=group)
+    """Non-blocking point-to-point send of a contiguous block of per-frame tensors (tokens) to its owner.  RCCL sends
+    are ordered on the stream that produced the block; a host-side backend (gloo, used to rehearse the rank logic) reads
+    the memory from the CPU, so the producing stream is drained first."""
+    block = block.contiguous()
+    if block.is_cuda and dist.get_backend(group) != "nccl":
+        torch.cuda.current_stream(block.device).synchronize()
+    return dist.isend(block, dst=dst, group=group)
 
 
 def recv_frames(shape, dtype, device, src: int = 0, group=None) -> torch.Tensor:

@@ -70,3 +70,61 @@ def test_two_ranks_exchange_their_shards():
             p.join(timeout=400)
     assert all(p.exitcode == 0 for p in procs)
     assert flags == [{"sparse": True, "dense": True}] * 2
+
+
+def _harness_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from audio_motion_avatar_amd import ops
+        from audio_motion_avatar_amd.harness import AudioDrivenAvatar
+        from audio_motion_avatar_amd.synthetic import init_random_heads, make_render_inputs
+        from test_audio_net_gpu import randomize, small_cfg
+
+        cfg = small_cfg()
+        torch.manual_seed(1234)  # every parameter the constructors draw: identical replicas on both ranks
+        model = AudioDrivenAvatar(cfg)
+        randomize(model.audio_triplane.transformer, 21)
+        init_random_heads(model.renderer)
+        model = model.cuda()
+        T, W = 3, 2
+        _, _, cam = make_render_inputs(T * W, cfg.renderer, seed=8, batch=1)
+        g = torch.Generator().manual_seed(3)
+        audio = torch.randn(1, T * W, 48, generator=g).cuda()
+        tri = torch.randn(1, 2, 32, 192, generator=g).cuda()
+        smpl = (torch.randn(1, 2, 32, 10, generator=g) * 0.2).cuda()
+        ref = model.rollout(tri, smpl, audio, cam)["images"][0]  # the exact chain, on this rank alone
+        want = ops.frames_to_rgb8(torch.cat([ref, torch.ones_like(ref[..., :1])], dim=-1).contiguous())
+        seq = model.rollout_sharded(tri, smpl, audio, cam, mode="sequential")
+        seg = model.rollout_sharded(tri, smpl, audio, cam, mode="segment")
+        # segment mode restarts rank 1's window from the reference tokens: its first window equals the chain's first
+        ok = {"sequential": bool(torch.equal(seq, want)),
+              "segment_rank0_block": bool(torch.equal(seg[:T], want[:T])),
+              "segment_rank1_block_is_a_fresh_chain": bool(seg.shape == want.shape and not torch.equal(seg[T:], want[T:]))}
+        flags = [None] * world
+        dist.all_gather_object(flags, ok)
+        if rank == 0:
+            out.put(flags)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_sequential_and_segment_rollout():
+    """harness.rollout_sharded on two ranks: "sequential" (rank 0 runs the one chain and sends rank 1 its token block)
+    reproduces the single-GPU clip on both ranks; "segment" gives rank 1 a chain of its own."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_harness_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        flags = q.get(timeout=400)
+    finally:
+        for p in procs:
+            p.join(timeout=400)
+    assert all(p.exitcode == 0 for p in procs)
+    assert flags == [{"sequential": True, "segment_rank0_block": True, "segment_rank1_block_is_a_fresh_chain": True}] * 2
