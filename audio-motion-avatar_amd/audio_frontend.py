@@ -49,22 +49,37 @@ def extract_audio_features(waveform, sr, frames_count, model, clip_length=8, sam
         waveform = waveform[:, : int(video_duration * sample_rate)]
         audio_duration = video_duration
     frame_duration = audio_duration / frames_count
-    features = []
-    for start_idx in range(0, frames_count, clip_length):                    # :68-105
+    # clip boundaries as the reference cuts them (:68-89) ...
+    clips = []
+    for start_idx in range(0, frames_count, clip_length):
         end_idx = min(start_idx + clip_length, frames_count)
         start_sample = int(start_idx * frame_duration * sample_rate)
         end_sample = min(int(end_idx * frame_duration * sample_rate), waveform.shape[1])
         if start_sample >= end_sample:
             start_sample = max(0, waveform.shape[1] - int((end_idx - start_idx) * frame_duration * sample_rate))
             end_sample = waveform.shape[1]
-        clip = _normalize(waveform[0, start_sample:end_sample])
-        hidden = model(clip[None]).last_hidden_state                        # [1, steps, hidden]
-        steps = hidden.shape[1]
-        frames_in_clip = end_idx - start_idx
+        clips.append((start_sample, end_sample, end_idx - start_idx))
+    # ... but clips of equal length go through the model as ONE batch (the reference feeds them one by one on the
+    # CPU): the base model has no cross-sample operation -- GroupNorm in the feature extractor and the positional
+    # convolution are per sample, there is no padding and hence no attention mask -- so each row of the batch is the
+    # clip's own result up to GEMM summation order.
+    hidden_of = [None] * len(clips)
+    by_length = {}
+    for ci, (a, b, _) in enumerate(clips):
+        by_length.setdefault(b - a, []).append(ci)
+    for members in by_length.values():
+        batch = torch.stack([_normalize(waveform[0, clips[ci][0]:clips[ci][1]]) for ci in members])
+        hidden = model(batch).last_hidden_state                              # [clips, steps, hidden]
+        for row, ci in enumerate(members):
+            hidden_of[ci] = hidden[row]
+    features = []
+    for ci, (_, _, frames_in_clip) in enumerate(clips):                      # :94-105
+        hidden = hidden_of[ci]
+        steps = hidden.shape[0]
         per = max(1, steps // frames_in_clip)
         for i in range(frames_in_clip):
             a, b = min(i * per, steps - 1), min((i + 1) * per, steps)
-            features.append(hidden[0, a:b].mean(dim=0) if a < b else hidden[0, a])
+            features.append(hidden[a:b].mean(dim=0) if a < b else hidden[a])
     if len(features) < frames_count:                                         # :107-113
         features.extend([features[-1]] * (frames_count - len(features)))
     return torch.stack(features[:frames_count])
