@@ -318,3 +318,91 @@ extern "C" int amav_geglu(int64_t rows, int inner, const float *proj, int64_t pr
         quads, inner / 4, reinterpret_cast<const float4 *>(proj), proj_row_stride / 4, reinterpret_cast<float4 *>(out));
     return check_launch("amav_geglu");
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Residual adds + LayerNorm of BasicTransformerBlock (src/models/transformers.py:292-399) in one pass:
+//   h = (a + h);  h = (row_b + h);  n = LayerNorm(h) * w + b
+// i.e. `attn1(...) + h`, then `attn2(...) + h` whose value is ONE row per batch item (single audio key), then norm3.
+// torch runs two adds and two LayerNorms for this (norm2's result is never used on this path: the cross-attention
+// output does not depend on its queries).  One wave per row, row in registers, two-pass mean / variance.
+namespace amav {
+namespace attn {
+template <int kVec>  // float4 per lane: dim = 256 * kVec
+__global__ __launch_bounds__(256) void add_layernorm_kernel(long long rows, long long rows_per_batch,
+                                                            const float4 *__restrict__ a, const float4 *__restrict__ brow,
+                                                            const float4 *__restrict__ h, float4 *__restrict__ h_out,
+                                                            const float4 *__restrict__ w,
+                                                            const float4 *__restrict__ b, float eps,
+                                                            float4 *__restrict__ out) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    constexpr int kRow4 = 64 * kVec;
+    const float4 *br = brow ? brow + (row / rows_per_batch) * kRow4 : nullptr;
+    float4 x[kVec];
+    float sum = 0.f;
+#pragma unroll
+    for (int v = 0; v < kVec; ++v) {
+        const int c = lane + 64 * v;
+        float4 t = h[row * kRow4 + c];
+        if (a) {
+            const float4 av = a[row * kRow4 + c];
+            t = make_float4(av.x + t.x, av.y + t.y, av.z + t.z, av.w + t.w);
+        }
+        if (br) {
+            const float4 rv = br[c];
+            t = make_float4(rv.x + t.x, rv.y + t.y, rv.z + t.z, rv.w + t.w);
+        }
+        x[v] = t;
+        h_out[row * kRow4 + c] = t;
+        sum += (t.x + t.y) + (t.z + t.w);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    const float mean = sum * (1.0f / (256.0f * kVec));
+    float var = 0.f;
+#pragma unroll
+    for (int v = 0; v < kVec; ++v) {
+        const float dx = x[v].x - mean, dy = x[v].y - mean, dz = x[v].z - mean, dw = x[v].w - mean;
+        var += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o, 64);
+    const float rstd = 1.0f / sqrtf(var * (1.0f / (256.0f * kVec)) + eps);
+#pragma unroll
+    for (int v = 0; v < kVec; ++v) {
+        const int c = lane + 64 * v;
+        const float4 wv = w[c], bv = b[c];
+        out[row * kRow4 + c] = make_float4((x[v].x - mean) * rstd * wv.x + bv.x, (x[v].y - mean) * rstd * wv.y + bv.y,
+                                           (x[v].z - mean) * rstd * wv.z + bv.z, (x[v].w - mean) * rstd * wv.w + bv.w);
+    }
+}
+}  // namespace attn
+}  // namespace amav
+
+extern "C" int amav_add_layernorm(int64_t rows, int dim, int64_t rows_per_batch, const float *add, const float *batch_row,
+                                  const float *hidden, float *hidden_out, const float *weight, const float *bias,
+                                  float eps, float *out_norm, void *stream_) {
+    AMAV_REQUIRE(rows > 0 && rows_per_batch > 0 && (dim == 256 || dim == 512 || dim == 768 || dim == 1024),
+                 "amav_add_layernorm: rows=%lld dim=%d (dim must be 256, 512, 768 or 1024)", (long long)rows, dim);
+    AMAV_REQUIRE(hidden && hidden_out && weight && bias && out_norm, "amav_add_layernorm: NULL pointer");
+    AMAV_REQUIRE(((reinterpret_cast<uintptr_t>(hidden) | reinterpret_cast<uintptr_t>(hidden_out) |
+                   reinterpret_cast<uintptr_t>(out_norm) |
+                   reinterpret_cast<uintptr_t>(add) | reinterpret_cast<uintptr_t>(batch_row) |
+                   reinterpret_cast<uintptr_t>(weight) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0,
+                 "amav_add_layernorm: buffers must be 16-byte aligned");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const unsigned grid = (unsigned)((rows + 3) / 4);
+    auto p4 = [](const float *p) { return reinterpret_cast<const float4 *>(p); };
+    float4 *h4 = reinterpret_cast<float4 *>(hidden_out), *o4 = reinterpret_cast<float4 *>(out_norm);
+#define AMAV_LN_LAUNCH(V) \
+    amav::attn::add_layernorm_kernel<V><<<grid, 256, 0, stream>>>(rows, rows_per_batch, p4(add), p4(batch_row), \
+                                                                  p4(hidden), h4, p4(weight), p4(bias), eps, o4)
+    if (dim == 256) AMAV_LN_LAUNCH(1);
+    else if (dim == 512) AMAV_LN_LAUNCH(2);
+    else if (dim == 768) AMAV_LN_LAUNCH(3);
+    else AMAV_LN_LAUNCH(4);
+#undef AMAV_LN_LAUNCH
+    return check_launch("amav_add_layernorm");
+}

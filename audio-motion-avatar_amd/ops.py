@@ -469,3 +469,26 @@ def geglu(proj):
     check(_lib.lib().amav_geglu(proj.numel() // proj.shape[-1], inner, proj.data_ptr(), proj.shape[-1], out.data_ptr(),
                                 _stream()), "amav_geglu")
     return out
+
+
+def add_layernorm(hidden, add, batch_row, weight, bias, eps=1e-5):
+    """hidden [B,S,dim] (contiguous), add [B,S,dim] or None, batch_row [B,1,dim] or None ->
+    (h = batch_row + (add + hidden), LayerNorm(h) * weight + bias), two new tensors.  transformers.py:292-399."""
+    hidden = _need(hidden, "hidden")
+    if hidden.dim() != 3 or not hidden.is_contiguous():
+        raise AmavError("add_layernorm: hidden must be a contiguous [B,S,dim] tensor")
+    B, S, dim = hidden.shape
+    ptr = lambda t, name, shape: None if t is None else _shaped(t, name, shape).data_ptr()
+    h_out, out = torch.empty_like(hidden), torch.empty_like(hidden)
+    check(_lib.lib().amav_add_layernorm(B * S, dim, S, ptr(add, "add", (B, S, dim)), ptr(batch_row, "batch_row", (B, 1, dim)),
+                                        hidden.data_ptr(), h_out.data_ptr(), _shaped(weight, "weight", (dim,)).data_ptr(),
+                                        _shaped(bias, "bias", (dim,)).data_ptr(), float(eps), out.data_ptr(), _stream()),
+          "amav_add_layernorm")
+    return h_out, out
+
+
+def _shaped(t, name, shape):
+    t = _need(t, name)
+    if tuple(t.shape) != tuple(shape) or not t.is_contiguous():
+        raise AmavError(f"{name}: expected a contiguous tensor of shape {tuple(shape)}, got {tuple(t.shape)}")
+    return t

@@ -238,6 +238,14 @@ int amav_selfattn_forward(int batch, int seq_len, int heads, int head_dim, const
  * proj [rows, 2*inner] (row stride in floats) -> out [rows, inner] = proj[:, :inner] * gelu(proj[:, inner:]). */
 int amav_geglu(int64_t rows, int inner, const float *proj_dev, int64_t proj_row_stride, float *out_dev, void *stream);
 
+/* Residual adds + LayerNorm of BasicTransformerBlock (src/models/transformers.py:292-399) in one pass over [rows, dim]
+ * (dim in {256, 512, 768, 1024}):  h = (add + hidden);  h = (batch_row[row / rows_per_batch] + h);  hidden_out = h;
+ * out_norm = LayerNorm(h) * weight + bias.  `add` [rows, dim] and `batch_row` [batches, dim] may be NULL; hidden_out
+ * may alias hidden. */
+int amav_add_layernorm(int64_t rows, int dim, int64_t rows_per_batch, const float *add_dev, const float *batch_row_dev,
+                       const float *hidden_dev, float *hidden_out_dev, const float *weight_dev, const float *bias_dev,
+                       float eps, float *out_norm_dev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

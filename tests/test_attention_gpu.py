@@ -69,3 +69,27 @@ def test_fused_geglu_matches_torch():
     want64 = (h.double() * F.gelu(gate.double())).float()
     assert got.shape == (3, 257, 2048)
     assert torch.allclose(got, want, rtol=2e-6, atol=2e-6) and torch.allclose(got, want64, rtol=2e-6, atol=2e-6)
+
+
+@pytest.mark.parametrize("dim", [256, 512])
+def test_fused_residual_adds_and_layernorm(dim):
+    """ops.add_layernorm == the block's `attn1 + h`, `attn2 + h` (one row per batch item) and norm3
+    (transformers.py:292-399)."""
+    import torch.nn.functional as F
+
+    from audio_motion_avatar_amd import ops
+
+    g = torch.Generator().manual_seed(dim)
+    B, S = 2, 777
+    h = torch.randn(B, S, dim, generator=g).cuda()
+    a = torch.randn(B, S, dim, generator=g).cuda()
+    row = torch.randn(B, 1, dim, generator=g).cuda()
+    w = (1 + 0.1 * torch.randn(dim, generator=g)).cuda()
+    b = (0.1 * torch.randn(dim, generator=g)).cuda()
+    h_out, n = ops.add_layernorm(h, a, row, w, b, 1e-5)
+    want_h = row + (a + h)
+    assert torch.equal(h_out, want_h)
+    want_n = F.layer_norm(want_h.double(), (dim,), w.double(), b.double(), 1e-5)
+    assert (n.double() - want_n).abs().max().item() <= 5e-6
+    h2, n2 = ops.add_layernorm(h, None, None, w, b, 1e-5)
+    assert torch.equal(h2, h) and (n2.double() - F.layer_norm(h.double(), (dim,), w.double(), b.double(), 1e-5)).abs().max() <= 5e-6
