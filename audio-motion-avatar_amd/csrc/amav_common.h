@@ -36,6 +36,10 @@ inline int check_launch(const char *what) {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Zero `bytes` on `stream` with an ordinary kernel launch (api.hip).  Used instead of hipMemsetAsync so that a captured
+// step holds kernel nodes only (HIP-graph note).
+hipError_t zero_async(void *ptr, size_t bytes, hipStream_t stream);
+
 // Bump allocator over the caller's workspace; with base == nullptr it only measures.
 struct Carver {
     char *base;

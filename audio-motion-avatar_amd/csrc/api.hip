@@ -1,4 +1,6 @@
 // Library-level entry points of libamav_hip.so (version, errors, device probe) and the camera kernel.
+#include <cstdlib>
+
 #include "amav_common.h"
 
 namespace amav {
@@ -6,6 +8,35 @@ namespace amav {
 char *error_buffer() {
     static thread_local char buf[512] = {0};
     return buf;
+}
+
+// 0 = zero-fill kernel (default), 1 = hipMemsetAsync (AMAV_CLEAR=memset, diagnostic only)
+static int clear_mode() {
+    static const int mode = [] {
+        const char *e = getenv("AMAV_CLEAR");
+        return (e && e[0] == 'm') ? 1 : 0;
+    }();
+    return mode;
+}
+
+__global__ __launch_bounds__(256) void zero_words_kernel(unsigned *__restrict__ dst, size_t words) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t quads = words >> 2;
+    if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+        if (i < quads) reinterpret_cast<uint4 *>(dst)[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (i < (words & 3)) dst[quads * 4 + i] = 0u;
+    } else {
+        for (size_t k = i * 4; k < min(words, i * 4 + 4); ++k) dst[k] = 0u;
+    }
+}
+
+hipError_t zero_async(void *ptr, size_t bytes, hipStream_t stream) {
+    if (bytes == 0) return hipSuccess;
+    if (clear_mode() == 1 || (bytes & 3) || (reinterpret_cast<uintptr_t>(ptr) & 3))
+        return hipMemsetAsync(ptr, 0, bytes, stream);
+    const size_t words = bytes / 4, threads = (words + 3) / 4;
+    zero_words_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, stream>>>(static_cast<unsigned *>(ptr), words);
+    return hipGetLastError();
 }
 
 // One thread per frame.  Replaces src/models/renderer.py:486-510 + src/utils/graphic_utils.py:67-78,103-145.

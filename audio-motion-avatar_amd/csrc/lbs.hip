@@ -424,7 +424,7 @@ extern "C" int amav_lbs_forward(int F, const amav_body_tables *tb, const float *
     // padded frame columns of featT must be finite (they feed FMAs whose results are discarded), and the MFMA path
     // reads kMfmaKPad zero rows past the table
     const size_t feat_rows = (size_t)t.KB + (FT ? 0 : kMfmaKPad);
-    if ((Fpad != F || FT == 0) && hipMemsetAsync(featT, 0, feat_rows * Fpad * sizeof(float), stream) != hipSuccess)
+    if ((Fpad != F || FT == 0) && zero_async(featT, feat_rows * Fpad * sizeof(float), stream) != hipSuccess)
         return fail(AMAV_ERR_LAUNCH, "amav_lbs_forward: hipMemsetAsync failed");
     float *A_dst = out_A ? out_A : A;
     joint_chain_kernel<<<F, 64, 0, stream>>>(t, F, Fpad, full_pose, coeffs, featT, A_dst);

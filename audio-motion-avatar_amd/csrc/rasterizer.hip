@@ -1073,7 +1073,7 @@ extern "C" int amav_rasterize_forward(const amav_raster_args *a, void *stream_) 
                         a->rotations.frame_stride == a->means3d.frame_stride &&
                         a->scales.frame_stride == a->means3d.frame_stride &&
                         a->colors.frame_stride == a->means3d.frame_stride;
-    if (hipMemsetAsync(p.buf.status, 0, sizeof(Status), stream) != hipSuccess)
+    if (zero_async(p.buf.status, sizeof(Status), stream) != hipSuccess)
         return fail(AMAV_ERR_LAUNCH, "amav_rasterize_forward: hipMemsetAsync failed");
 
     if (packed)

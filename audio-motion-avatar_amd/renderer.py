@@ -83,7 +83,6 @@ class Renderer(nn.Module):
         nn.init.constant_(self.gaussian_decoder.scaling_layer.bias, -1.0)
         nn.init.constant_(self.gaussian_decoder.opacity_layer.bias, inverse_sigmoid(0.1))
         self._packed = None
-        self._side_stream = None
         self._chunk_streams = []
         self.to(cfg.device)
 
@@ -160,32 +159,17 @@ class Renderer(nn.Module):
     def gaussians_from_tokens(self, triplane_tokens, smpl_params, out=None, side_work=None):
         """renderer.py:127-181 as one fused stage: tokens [F,C,3R^2] + SMPL-X params -> packed Gaussians [F,N,16].
 
-        The triplane projection (HBM streaming) does not depend on the body model, so it runs on a side stream
-        while the LBS chain (latency/VALU bound) runs on the current one; the densify + subset gather is folded
-        into the sampling kernel.  `side_work`: optional callable run on the side stream after the projection (the
-        camera kernel rides there, off the critical path); its result is returned as a second value.
+        Everything is enqueued on the calling stream: slab projection, camera set-up (`side_work`, an optional
+        callable whose result is returned as a second value), LBS chain, then the sampling kernel with the densify +
+        subset gather folded in.  (Round 1 ran the projection on a helper stream; measured worth nothing -- 1.148 vs
+        1.137 ms per 250-frame step -- and a fork/join graph only hid the hipMemsetAsync replay fault described in
+        DESIGN.md section 1.)
         """
         F = triplane_tokens.shape[0]
         w_plane, w_point = self._head_weights()
-        cur = torch.cuda.current_stream()
-        if self._side_stream is None:
-            self._side_stream = {}
-        side = self._side_stream.get(cur.cuda_stream)
-        if side is None:  # one helper stream per calling stream (render_tokens runs chunks on several)
-            side = self._side_stream[cur.cuda_stream] = torch.cuda.Stream(device=triplane_tokens.device)
-        side.wait_stream(cur)
-        side_result = None
-        with torch.cuda.stream(side):
-            proj = ops.triplane_project(triplane_tokens, w_plane, self._plane_resolution(triplane_tokens))
-            if side_work is not None:
-                side_result = side_work()
+        proj = ops.triplane_project(triplane_tokens, w_plane, self._plane_resolution(triplane_tokens))
+        side_result = side_work() if side_work is not None else None
         vertices = self._posed_vertices(smpl_params)
-        cur.wait_stream(side)
-        proj.record_stream(cur)  # made on the helper stream, consumed (and later freed) on this one
-        if isinstance(side_result, (tuple, list)):
-            for t_ in side_result:
-                if isinstance(t_, torch.Tensor):
-                    t_.record_stream(cur)
         transl = smpl_params["transl"].reshape(F, 3).float()
         if self.cfg.densify_smplx_verts:
             packed = ops.triplane_sample_decode_indexed(proj, vertices, self._gather_idx, transl, self.cfg.radius,
