@@ -189,10 +189,19 @@ def _npz_arrays(path: str, num_betas: int, num_expr: int, flat_hand_mean: bool):
     if not flat_hand_mean:
         pose_mean[75:120] = np.asarray(data["hands_meanl"], dtype=np.float64)
         pose_mean[120:165] = np.asarray(data["hands_meanr"], dtype=np.float64)
+    # smplx (body_models.py, SMPL / SMPLX.__init__): a model file with fewer than 300 + 100 components is the "10
+    # shape + 10 expression" release (SMPL-X v1.0), whose expression directions sit at 10:20
+    if shapedirs_all.ndim < 3:
+        shapedirs_all = shapedirs_all[:, :, None]
+    if shapedirs_all.shape[-1] < 400:
+        num_betas, num_expr = min(num_betas, 10), min(num_expr, 10)
+        expr_start = 10
+    else:
+        expr_start = 300
     return dict(v_template=np.asarray(data["v_template"], dtype=np.float64),
                 faces=np.asarray(data["f"]).astype(np.int64),
                 shapedirs=shapedirs_all[:, :, :num_betas],
-                expr_dirs=shapedirs_all[:, :, 300:300 + num_expr],
+                expr_dirs=shapedirs_all[:, :, expr_start:expr_start + num_expr],
                 posedirs=posedirs,
                 J_regressor=np.asarray(data["J_regressor"], dtype=np.float64),
                 lbs_weights=np.asarray(data["weights"], dtype=np.float64),

@@ -45,8 +45,16 @@ class AudioDrivenAvatar(nn.Module):
 
     # ---- checkpoint ----------------------------------------------------------------------------------------------
     def load_reference_checkpoint(self, path_or_state, strict=False):
-        """Load the tensors of a reference checkpoint; returns (missing, unexpected) of the audio_triplane load.
-        Uses torch.load(weights_only=True): nothing from the file is executed."""
+        """Load the tensors of a reference checkpoint (`checkpoint['state_dict']` with the `audio_triplane.` /
+        `triplane_gaussian.renderer.` prefixes, main2.py:127-138).  Uses torch.load(weights_only=True): nothing from
+        the file is executed.
+
+        Only keys of modules this build does not have are dropped (`point_encoder.*` / `point_refiner.*`: the PTv3
+        refiner; `smplx_model.*`: buffers that come from the SMPL-X file; `triplane_upsampler.*` only when this Renderer
+        was built without one).  A parameter of a module that EXISTS here and is absent from the checkpoint is an
+        error -- it would silently stay at its random initialisation -- unless the checkpoint has no entry at all
+        under that module's prefix and `strict` is off (a file saved without the renderer, or without the audio net).
+        Returns (missing, unexpected) accumulated over both loads; with `strict` unexpected keys raise too."""
         state = path_or_state
         if isinstance(path_or_state, str):
             state = torch.load(path_or_state, map_location="cpu", weights_only=True)
@@ -56,13 +64,30 @@ class AudioDrivenAvatar(nn.Module):
         # the renderer appears under both prefixes (it is one shared module); take whichever is present
         rend = {k[len("triplane_gaussian.renderer."):]: v for k, v in state.items()
                 if k.startswith("triplane_gaussian.renderer.")}
-        drop = ("point_encoder.", "point_refiner.", "triplane_upsampler.", "smplx_model.")  # 8(f) rows / file buffers
-        audio = {k: v for k, v in audio.items() if not k.startswith(tuple("renderer." + d for d in drop))}
+        drop = ["point_encoder.", "point_refiner.", "smplx_model."]  # 8(f) rows / buffers of the SMPL-X file
+        if not hasattr(self.renderer, "triplane_upsampler"):
+            drop.append("triplane_upsampler.")
+        drop = tuple(drop)
+        # the shared renderer's tensors, from whichever prefix carries them
+        for k in [k for k in audio if k.startswith("renderer.")]:
+            rend.setdefault(k[len("renderer."):], audio.pop(k))
         rend = {k: v for k, v in rend.items() if not k.startswith(drop)}
-        result = self.audio_triplane.load_state_dict(audio, strict=strict)
-        if rend:
-            self.renderer.load_state_dict(rend, strict=False)
-        return result
+        missing, unexpected = [], []
+        if audio or strict:
+            own = {k: v for k, v in self.audio_triplane.state_dict().items() if not k.startswith("renderer.")}
+            missing += [k for k in own if k not in audio]
+            unexpected += [k for k in audio if k not in own]
+            self.audio_triplane.load_state_dict({k: v for k, v in audio.items() if k in own}, strict=False)
+        if rend or strict:
+            r = self.renderer.load_state_dict(rend, strict=False)
+            missing += ["renderer." + k for k in r.missing_keys]
+            unexpected += ["renderer." + k for k in r.unexpected_keys]
+        if missing:
+            raise KeyError(f"reference checkpoint lacks {len(missing)} tensors of modules this build runs (they would "
+                           f"stay randomly initialised): {missing[:8]}{' ...' if len(missing) > 8 else ''}")
+        if strict and unexpected:
+            raise KeyError(f"unexpected checkpoint keys: {unexpected[:8]}")
+        return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
 
     # ---- one window ----------------------------------------------------------------------------------------------
     @torch.no_grad()

@@ -438,6 +438,10 @@ def triplane_sample_features(planes, points, radius):
 
 
 # ------------------------------------------------------------------------------------------------------ attention
+# A list of (Event, Event) pairs: every selfattn() call pops one and records it around its kernels (bench.py)
+ATTN_PROFILE_EVENTS = None
+
+
 def selfattn(q, k, v, heads, scale=None):
     """softmax(q k^T * scale) v for [B,S,H*D] fp32 tensors (row stride may exceed H*D), D = 64."""
     for name, t in (("q", q), ("k", k), ("v", v)):
@@ -453,9 +457,14 @@ def selfattn(q, k, v, heads, scale=None):
     if nbytes == 0:
         raise AmavError(f"amav_selfattn_workspace_bytes rejected B={B} S={S} H={heads} D={D}")
     ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
+    ev = ATTN_PROFILE_EVENTS.pop(0) if ATTN_PROFILE_EVENTS else None
+    if ev is not None:
+        ev[0].record()
     check(_lib.lib().amav_selfattn_forward(B, S, heads, D, q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(1),
                                            out.data_ptr(), HD, float(scale if scale is not None else D ** -0.5),
                                            ws.data_ptr(), nbytes, _stream()), "amav_selfattn_forward")
+    if ev is not None:
+        ev[1].record()
     return out
 
 

@@ -48,6 +48,9 @@ class Attention(nn.Module):
         if attention_mask is not None:
             raise NotImplementedError("attention masks are not used on this path (transformers.py:1026-1031)")
         if encoder_hidden_states is None:
+            if torch.is_grad_enabled() and (hidden_states.requires_grad or self.to_q.weight.requires_grad):
+                raise NotImplementedError("the MFMA self-attention kernel is inference-only (no backward): run under "
+                                          "torch.no_grad() / inference_mode (INTEGRATION.md)")
             B, S, _ = hidden_states.shape
             qkv = F.linear(hidden_states, self._qkv_weight())          # [B,S,3*inner], one GEMM
             i = self.inner_dim

@@ -1,0 +1,457 @@
+#!/usr/bin/env python3
+"""Golden vectors produced by RUNNING THE REFERENCE'S OWN PYTHON (read-only, from /root/reference) on the CPU of the
+build container.  Output: tests/golden/ref_*.npz (+ ref_manifest.json).  Nothing of the reference travels: the
+fixtures hold inputs, seeds, parameter names / shapes and outputs only.
+
+Why placeholders.  The reference's modules import third-party packages that are absent from this image (omegaconf,
+diffusers, smplx, pytorch3d, ...).  Those packages stay absent.  To let `import
+src.models.transformers` get past its import statements, every absent top-level package is mapped to an INERT
+placeholder module: attribute access yields placeholder classes that do nothing.  They are inert by construction:
+
+  * during the IMPORT phase a placeholder may be named (`from diffusers... import Attention`), used as a base class or
+    applied as a decorator (recorded; a decorated class is listed in the manifest as `decorated_by_placeholder`);
+  * during the RUN phase (everything that produces fixture data) ANY call, instantiation or attribute use of a
+    placeholder raises PlaceholderUsed, so a value that reaches a fixture cannot have flowed through one.  The script
+    also asserts at the end that the run phase recorded zero placeholder uses.
+
+Two tiers of fixtures (the tier is stored in every file and in the manifest):
+
+  tier 1  reference functions / classes executed exactly as shipped, through their own constructors:
+            camera      getWorld2View2_torch, getProjectionMatrix_torch, focal2fov_torch
+                        (src/utils/graphic_utils.py:67-78,103-136,144-145) in the call sequence of
+                        render_one (src/models/renderer.py:486-510)
+            reducers    TriPlaneTemporalReducer, SMPLXTemporalReducer in eval mode (src/models/triplane_audio_net.py:7-89)
+            feedforward GEGLU, FeedForward (src/models/transformers.py:402-452,484-508)
+            triplane    Renderer.sample_from_triplane, Renderer.construct_gaussians (src/models/renderer.py:292-346;
+                        plain functions of the class, called with a namespace carrying cfg.radius as `self`),
+                        TriplaneUpsampler / UpsampleBlock / ResBlock (renderer.py:348-417), inverse_sigmoid
+  tier 2  reference code executed through its own constructors and forwards, with ONE named component injected in
+          place of an absent third-party class (the injected component is the build's restatement and stays
+          "parity unpinned"; what the fixture pins is everything around it):
+            audio_net   AudioTriplaneNet.__init__/forward, Transformer1D_nn, BasicTransformerBlock, FeedForward, the
+                        reducers (triplane_audio_net.py:92-271, transformers.py:140-399,912-1074) with
+                        `src.models.transformers.Attention` := torch restatement of diffusers' Attention as configured
+                        (q/k/v bias-free, out bias, SDPA, scale 1/sqrt(d)); renderer := recorder
+            smplx_decoder SMPLXDecoder.__init__/forward (src/models/smplx_decoder.py:40-145) with
+                        rotation_6d_to_matrix / matrix_to_axis_angle := oracle/rotation.py (pytorch3d restatement)
+
+Parameters are not stored: after a reference module is built, every entry of its state_dict is overwritten by
+`seeded_tensor(name, shape)` below, a pure function of the parameter's NAME; the tests rebuild the same values for
+the product modules (which must therefore expose the same names and shapes -- SURVEY Appendix B).
+
+Run:  python tests/golden/make_reference_golden.py      (needs /root/reference; CPU only)
+"""
+import importlib
+import importlib.abc
+import importlib.machinery
+import importlib.util
+import json
+import math
+import os
+import sys
+import types
+import zlib
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REFERENCE = os.environ.get("AMAV_REFERENCE", "/root/reference")
+
+PHASE = {"name": "import"}
+IMPORT_EVENTS = []  # (placeholder, what) during import
+RUN_EVENTS = []     # must stay empty
+
+
+class PlaceholderUsed(RuntimeError):
+    pass
+
+
+class _PlaceholderMeta(type):
+    def __call__(cls, *args, **kwargs):
+        if PHASE["name"] != "import":
+            RUN_EVENTS.append((cls.__qualname__, "call"))
+            raise PlaceholderUsed(f"placeholder {cls.__qualname__} was called in the run phase")
+        if cls.__dict__.get("_is_subclass"):
+            IMPORT_EVENTS.append((cls.__qualname__, "instantiated at import"))
+            raise PlaceholderUsed(f"{cls.__qualname__}: a subclass of a placeholder was instantiated at import")
+        if len(args) == 1 and not kwargs and (isinstance(args[0], type) or callable(args[0])):
+            target = args[0]
+            IMPORT_EVENTS.append((cls.__qualname__, f"decorated {getattr(target, '__qualname__', target)!s}"))
+            try:
+                target._decorated_by_placeholder = cls.__qualname__
+            except Exception:
+                pass
+            return target  # an inert decorator leaves its target alone
+        IMPORT_EVENTS.append((cls.__qualname__, "called at import"))
+        return make_placeholder(cls.__qualname__ + "()")  # e.g. REGISTRY = Registry("x"): still inert
+
+    def __getattr__(cls, name):
+        if name.startswith("__") and name.endswith("__"):
+            raise AttributeError(name)
+        if PHASE["name"] != "import":
+            RUN_EVENTS.append((cls.__qualname__, f"getattr {name}"))
+            raise PlaceholderUsed(f"placeholder {cls.__qualname__}.{name} was used in the run phase")
+        return make_placeholder(f"{cls.__qualname__}.{name}")
+
+    def __init_subclass__(cls, **kw):  # pragma: no cover
+        pass
+
+
+def make_placeholder(qualname):
+    return _PlaceholderMeta(qualname.split(".")[-1] or "placeholder", (), {"__qualname__": qualname,
+                                                                              "_placeholder": True})
+
+
+class _PlaceholderModule(types.ModuleType):
+    def __getattr__(self, name):
+        if name.startswith("__") and name.endswith("__"):
+            raise AttributeError(name)
+        if PHASE["name"] != "import":
+            RUN_EVENTS.append((self.__name__, f"getattr {name}"))
+            raise PlaceholderUsed(f"placeholder module {self.__name__}.{name} was used in the run phase")
+        ph = make_placeholder(f"{self.__name__}.{name}")
+        setattr(self, name, ph)
+        return ph
+
+
+def absent_reference_imports():
+    """Top-level packages imported anywhere under REFERENCE/src that no finder of this image can resolve."""
+    import ast
+
+    names = set()
+    for dirpath, _, files in os.walk(os.path.join(REFERENCE, "src")):
+        for fn in files:
+            if fn.endswith(".py"):
+                try:
+                    tree = ast.parse(open(os.path.join(dirpath, fn), encoding="utf-8").read())
+                except SyntaxError:
+                    continue
+                for node in ast.walk(tree):
+                    if isinstance(node, ast.Import):
+                        names.update(a.name.split(".")[0] for a in node.names)
+                    elif isinstance(node, ast.ImportFrom) and node.level == 0 and node.module:
+                        names.add(node.module.split(".")[0])
+    absent = set()
+    for n in sorted(names - {"src"}):
+        try:
+            if importlib.util.find_spec(n) is None:
+                absent.add(n)
+        except (ImportError, ValueError):
+            absent.add(n)
+    return absent
+
+
+class _AbsentFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    """Serves an inert placeholder module for the packages that the reference imports and this image lacks (the set
+    is computed before the finder is registered, and the finder sits LAST in sys.meta_path)."""
+
+    def __init__(self, absent):
+        self.absent = set(absent)
+
+    def find_spec(self, fullname, path=None, target=None):
+        if fullname.split(".")[0] in self.absent and PHASE["name"] == "import":
+            return importlib.machinery.ModuleSpec(fullname, self, is_package=True)
+        return None
+
+    def create_module(self, spec):
+        m = _PlaceholderModule(spec.name)
+        m.__path__ = []
+        return m
+
+    def exec_module(self, module):
+        pass
+
+
+def install_placeholders():
+    absent = absent_reference_imports()
+    sys.meta_path.append(_AbsentFinder(absent))
+    return sorted(absent)
+
+
+def seeded_tensor(name, shape, dtype=torch.float32):
+    """Deterministic stand-in for trained weights: a pure function of the parameter NAME and shape.  Norm scales
+    ('norm*.weight', BatchNorm 'running_var') stay near 1 so the activations keep a sane range."""
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) & 0x7FFFFFFF)
+    leaf = name.rsplit(".", 1)[-1]
+    t = torch.randn(tuple(shape), generator=g, dtype=torch.float64)
+    is_norm = ".norm" in "." + name or "norm" in name.split(".")[-2:][0] or "block.0." in name or "block.3." in name
+    if leaf == "num_batches_tracked":
+        return torch.zeros(tuple(shape), dtype=torch.long)
+    if leaf == "running_var":
+        return (1.0 + 0.25 * t.abs()).to(dtype)
+    if leaf == "running_mean":
+        return (0.1 * t).to(dtype)
+    if leaf == "weight" and len(shape) == 1 and is_norm:
+        return (1.0 + 0.1 * t).to(dtype)
+    if leaf == "bias" or len(shape) == 1:
+        return (0.05 * t).to(dtype)
+    fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else int(shape[0])
+    return (t / math.sqrt(max(fan_in, 1))).to(dtype)
+
+
+def reseed_module(module):
+    """Overwrite every state_dict entry with seeded_tensor(name, shape); returns {name: shape}."""
+    sd = module.state_dict()
+    new = {k: seeded_tensor(k, v.shape, v.dtype if v.dtype.is_floating_point else torch.float32)
+           if v.dtype.is_floating_point else seeded_tensor(k, v.shape) for k, v in sd.items()}
+    module.load_state_dict(new)
+    return {k: list(v.shape) for k, v in sd.items()}
+
+
+def rnd(seed, *shape, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def save(name, tier, cites, arrays, meta=None):
+    path = os.path.join(HERE, f"ref_{name}.npz")
+    out = {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in arrays.items()}
+    out["_tier"] = np.asarray(tier)
+    out["_cites"] = np.asarray(json.dumps(cites))
+    out["_meta"] = np.asarray(json.dumps(meta or {}))
+    np.savez_compressed(path, **out)
+    return {"file": os.path.basename(path), "tier": tier, "cites": cites, "bytes": os.path.getsize(path),
+            "meta": meta or {}}
+
+
+# ------------------------------------------------------------------------------------------------------- fixtures
+def fixture_camera(gu):
+    """render_one's camera block (renderer.py:486-510) evaluated with the reference's own three functions."""
+    cams = []
+    g = torch.Generator().manual_seed(11)
+    specs = [(512, 512), (256, 256), (1296, 2304), (1024, 1024)]
+    K_all, E_all, hw = [], [], []
+    view_all, proj_all, full_all, campos_all, tan_all = [], [], [], [], []
+    for i, (h, w) in enumerate(specs):
+        f = float(w) * (1.0 + 0.2 * i)
+        K = torch.tensor([[f, 0.0, w / 2 + 3.0 * i], [0.0, f * 1.05, h / 2 - 2.0 * i], [0.0, 0.0, 1.0]])
+        ang = torch.randn(3, generator=g) * 0.3
+        cx, sx, cy, sy, cz, sz = (math.cos(ang[0]), math.sin(ang[0]), math.cos(ang[1]), math.sin(ang[1]),
+                                  math.cos(ang[2]), math.sin(ang[2]))
+        Rx = torch.tensor([[1, 0, 0], [0, cx, -sx], [0, sx, cx]], dtype=torch.float32)
+        Ry = torch.tensor([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]], dtype=torch.float32)
+        Rz = torch.tensor([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]], dtype=torch.float32)
+        E = torch.eye(4)
+        E[:3, :3] = Rz @ Ry @ Rx
+        E[:3, 3] = torch.tensor([0.0, 0.4, 2.4]) + torch.randn(3, generator=g) * 0.1
+        # ---- the reference's statements, renderer.py:489-510
+        R = E[:3, :3].reshape(3, 3).transpose(1, 0)
+        T = E[:3, 3]
+        znear, zfar = 0.01, 100.0
+        FovY = gu.focal2fov_torch(K[1, 1], h)
+        FovX = gu.focal2fov_torch(K[0, 0], w)
+        tanfovx = math.tan(FovX * 0.5)
+        tanfovy = math.tan(FovY * 0.5)
+        world_view = gu.getWorld2View2_torch(R, T).transpose(0, 1)
+        proj = gu.getProjectionMatrix_torch(znear=znear, zfar=zfar, fovX=FovX, fovY=FovY, K=K, w=w, h=h).transpose(0, 1)
+        full = (world_view.unsqueeze(0).bmm(proj.unsqueeze(0))).squeeze(0)
+        campos = world_view.inverse()[3, :3]
+        K_all.append(K), E_all.append(E), hw.append([h, w])
+        view_all.append(world_view), proj_all.append(proj), full_all.append(full), campos_all.append(campos)
+        tan_all.append([tanfovx, tanfovy])
+    return save("camera", 1, ["src/utils/graphic_utils.py:67-78,103-136,144-145", "src/models/renderer.py:486-510"],
+                dict(K=torch.stack(K_all), E=torch.stack(E_all), hw=np.asarray(hw), viewmatrix=torch.stack(view_all),
+                     projection=torch.stack(proj_all), full_proj=torch.stack(full_all), campos=torch.stack(campos_all),
+                     tanfov=np.asarray(tan_all, dtype=np.float64)))
+
+
+def fixture_reducers(tan):
+    C, R, L, B = 32, 4, 8, 2
+    tri = tan.TriPlaneTemporalReducer(C=C, time_steps=2).eval()
+    smp = tan.SMPLXTemporalReducer(C=C, time_steps=2).eval()
+    names = {"triplane_motion_encoder." + k: v for k, v in reseed_named(tri, "triplane_motion_encoder.").items()}
+    names.update({"smplx_motion_encoder." + k: v for k, v in reseed_named(smp, "smplx_motion_encoder.").items()})
+    x_tri = rnd(21, B, 2, 3, C, R, R)
+    x_smpl = rnd(22, B, 2, C, L)
+    with torch.no_grad():
+        y_tri, y_smpl = tri(x_tri), smp(x_smpl)
+    return save("reducers", 1, ["src/models/triplane_audio_net.py:7-42,44-89"],
+                dict(x_tri=x_tri, y_tri=y_tri, x_smpl=x_smpl, y_smpl=y_smpl),
+                meta=dict(C=C, R=R, L=L, params=names, mode="eval"))
+
+
+def reseed_named(module, prefix):
+    """reseed_module, but the seed of every entry uses `prefix + name` (the name it has inside the full model)."""
+    sd = module.state_dict()
+    module.load_state_dict({k: seeded_tensor(prefix + k, v.shape) for k, v in sd.items()})
+    return {k: list(v.shape) for k, v in sd.items()}
+
+
+def fixture_feedforward(tr):
+    dim = 64
+    ff = tr.FeedForward(dim, dropout=0.0, activation_fn="geglu", final_dropout=False).eval()
+    gl = tr.GEGLU(dim, 96).eval()
+    p_ff = reseed_named(ff, "ff.")
+    p_gl = reseed_named(gl, "geglu.")
+    x = rnd(31, 2, 50, dim, scale=2.0)
+    with torch.no_grad():
+        y_ff, y_gl = ff(x), gl(x)
+    return save("feedforward", 1, ["src/models/transformers.py:402-452,484-508"], dict(x=x, y_ff=y_ff, y_geglu=y_gl),
+                meta=dict(dim=dim, geglu_out=96, params_ff=p_ff, params_geglu=p_gl))
+
+
+def fixture_triplane(rd, mu):
+    ns = types.SimpleNamespace
+    C, R, N, B = 16, 8, 300, 2
+    self_like = ns(cfg=ns(radius=1.4))
+    planes = rnd(41, B, 3, C, R, R)
+    pts = rnd(42, B, N, 3, scale=0.9)
+    pts[:, :8] = torch.tensor([[1.4, -1.4, 0.0], [2.0, 0.3, -3.0], [0.0, 0.0, 0.0], [-1.4, 1.4, 1.4], [1.39999, 0.7, -0.7],
+                               [0.175, 0.175, 0.175], [-0.525, 1.225, 0.0], [1.5, -1.5, 1.5]])  # borders, clamped, texel centres
+    with torch.no_grad():
+        feats = rd.Renderer.sample_from_triplane(self_like, planes, pts)
+        feats_unbatched = rd.Renderer.sample_from_triplane(self_like, planes[0], pts[0])
+        gp = dict(xyz_offset=rnd(43, B, N, 3, scale=0.01), scaling=rnd(44, B, N, 3) - 1.0, rotation=rnd(45, B, N, 4),
+                  opacity=rnd(46, B, N, 1), shs=rnd(47, B, N, 3))
+        transl = rnd(48, B, 3, scale=0.2)
+        g = rd.Renderer.construct_gaussians(self_like, gp, pts, {"transl": transl})
+        ucfg = ns(triplane_feature_dim=C, num_upsample_blocks=2)
+        up = rd.TriplaneUpsampler(ucfg).eval()
+        p_up = reseed_named(up, "triplane_upsampler.")
+        up_in = rnd(49, 1, 3, C, 4, 4)
+        up_out = up(up_in)
+    arrays = dict(planes=planes, points=pts, features=feats, features_unbatched=feats_unbatched, transl=transl,
+                  up_in=up_in, up_out=up_out, inverse_sigmoid_0p1=np.asarray(mu.inverse_sigmoid(0.1)),
+                  inverse_sigmoid_t=mu.inverse_sigmoid(torch.tensor([0.1, 0.5, 0.9])))
+    arrays.update({"gp_" + k: v for k, v in gp.items()})
+    arrays.update({"g_" + k: v for k, v in g.items()})
+    return save("triplane", 1, ["src/models/renderer.py:292-317,319-346,348-417", "src/utils/math_utils.py:7-11"], arrays,
+                meta=dict(C=C, R=R, radius=1.4, num_upsample_blocks=2, params_upsampler=p_up, upsampler_mode="eval"))
+
+
+class OracleAttention(torch.nn.Module):
+    """INJECTED (tier 2): diffusers `Attention` as the reference configures it (transformers.py:226-234,250-260;
+    SURVEY Appendix A.3), restated with torch: to_q/to_k/to_v without bias, to_out = [Linear(bias), Dropout], no
+    norms, SDPA with scale 1/sqrt(dim_head).  Same constructor keywords and parameter names as diffusers'."""
+
+    def __init__(self, query_dim, cross_attention_dim=None, heads=8, dim_head=64, dropout=0.0, bias=False,
+                 upcast_attention=False):
+        super().__init__()
+        inner = heads * dim_head
+        ctx = cross_attention_dim if cross_attention_dim is not None else query_dim
+        self.heads = heads
+        self.to_q = torch.nn.Linear(query_dim, inner, bias=bias)
+        self.to_k = torch.nn.Linear(ctx, inner, bias=bias)
+        self.to_v = torch.nn.Linear(ctx, inner, bias=bias)
+        self.to_out = torch.nn.ModuleList([torch.nn.Linear(inner, query_dim), torch.nn.Dropout(dropout)])
+
+    def set_use_memory_efficient_attention_xformers(self, valid, attention_op=None):
+        assert not valid  # triplane_audio_net.py:139 passes enable_memory_efficient_attention=False
+
+    def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None):
+        assert attention_mask is None
+        ctx = hidden_states if encoder_hidden_states is None else encoder_hidden_states
+        B, S, _ = hidden_states.shape
+        split = lambda t: t.view(B, t.shape[1], self.heads, -1).transpose(1, 2)
+        q, k, v = split(self.to_q(hidden_states)), split(self.to_k(ctx)), split(self.to_v(ctx))
+        o = torch.nn.functional.scaled_dot_product_attention(q, k, v)
+        o = o.transpose(1, 2).reshape(B, S, -1)
+        return self.to_out[1](self.to_out[0](o))
+
+
+class RecordingRenderer(torch.nn.Module):
+    """INJECTED (tier 2) in place of Renderer at triplane_audio_net.py:269: records its arguments."""
+
+    def __init__(self):
+        super().__init__()
+        self.calls = []
+
+    def forward(self, tokens, cam_params, smpl_tokens):
+        self.calls.append((tokens, cam_params, smpl_tokens))
+        return "rendered_images", "gaussians", "smpl_params"
+
+
+def fixture_audio_net(tan, tr):
+    ns = types.SimpleNamespace
+    # reduced width with the head size the HIP kernel is built for (64): C = 32 channels, R = 4, L = 8 -> S = 112
+    c = ns(triplane_input_frames=2, triplane_output_frames=3, triplane_feature_dim=32, triplane_resolution=4,
+           smpl_token_len=8, smpl_token_dim=32, transformer_layers=2, transformer_head_dim=64, transformer_num_heads=1,
+           audio_feature_dim=24)
+    tr.Attention = OracleAttention  # the ONE injected component
+    rec = RecordingRenderer()
+    net = tan.AudioTriplaneNet(ns(model=ns(triplane_audio_net=c)), renderer=rec).eval()
+    shapes = {k: list(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict({k: seeded_tensor("audio_triplane." + k, v.shape) for k, v in net.state_dict().items()})
+    B = 2
+    audio = rnd(51, B, 5, c.audio_feature_dim)
+    tri = rnd(52, B, 2, 32, 3 * 16)
+    smpl = rnd(53, B, 2, 32, 8, scale=0.5)
+    cam = {"intrinsic": torch.zeros(B, 3, 3, 3), "extrinsic": torch.zeros(B, 3, 4, 4)}
+    with torch.no_grad():
+        out = net(audio, tri, None, cam, smpl)
+        one = net.transformer(torch.cat([tri[:, 0], smpl[:, 0], tri[:, 1], smpl[:, 1]], dim=-1), audio[:, :1])
+        blk = net.transformer.transformer_blocks[0]
+        bx = rnd(54, B, 40, 64)
+        by = blk(bx, encoder_hidden_states=audio[:, 1:2])
+    assert out[:3] == ("rendered_images", "gaussians", "smpl_params") and len(rec.calls) == 1
+    assert rec.calls[0][0] is out[3] and rec.calls[0][2] is out[4] and rec.calls[0][1] is cam
+    decorated = sorted(n for n, cls in vars(tr).items() if isinstance(cls, type) and
+                       not isinstance(cls, _PlaceholderMeta) and cls.__dict__.get("_decorated_by_placeholder"))
+    return save("audio_net", 2, ["src/models/triplane_audio_net.py:92-271", "src/models/transformers.py:140-399,912-1074"],
+                dict(audio=audio, tri=tri, smpl=smpl, out_tri=out[3], out_smpl=out[4], transformer_in_out=one,
+                     block_in=bx, block_out=by),
+                meta=dict(cfg=vars(c), params=shapes, param_prefix="audio_triplane.", injected=["src.models.transformers.Attention"
+                          " := OracleAttention (torch restatement of diffusers Attention, SURVEY A.3)",
+                          "renderer := RecordingRenderer"], decorated_by_placeholder=decorated, mode="eval"))
+
+
+def fixture_smplx_decoder(sd_mod):
+    sys.path.insert(0, ROOT)
+    from oracle import rotation as orot
+
+    sd_mod.rotation_6d_to_matrix = orot.rotation_6d_to_matrix  # the TWO injected functions (pytorch3d restatements)
+    sd_mod.matrix_to_axis_angle = orot.matrix_to_axis_angle
+    ns = types.SimpleNamespace
+    cfg = ns(smpl_token_dim=16, smpl_token_len=6, num_expression_coeffs=10)
+    dec = sd_mod.SMPLXDecoder(cfg).eval()
+    shapes = {k: list(v.shape) for k, v in dec.state_dict().items()}
+    dec.load_state_dict({k: seeded_tensor("smpl_decoder." + k, v.shape) for k, v in dec.state_dict().items()})
+    with torch.no_grad():  # make the 6-D heads large enough that the rotations are far from the identity
+        for n, m in dec.named_modules():
+            if n.startswith("dec_") and n.endswith("pose"):
+                m.weight.mul_(8.0)
+    tokens = rnd(61, 5, 16, 6)
+    with torch.no_grad():
+        out = dec(tokens)
+    arrays = {"tokens": tokens}
+    arrays.update({"out_" + k: v for k, v in out.items()})
+    return save("smplx_decoder", 2, ["src/models/smplx_decoder.py:40-145"], arrays,
+                meta=dict(cfg=vars(cfg), params=shapes, param_prefix="smpl_decoder.", pose_head_gain=8.0,
+                          injected=["rotation_6d_to_matrix, matrix_to_axis_angle := oracle/rotation.py "
+                                    "(pytorch3d restatements; downstream LBS only sees Rodrigues(aa) = M)"]))
+
+
+def main():
+    if not os.path.isdir(os.path.join(REFERENCE, "src")):
+        raise SystemExit(f"{REFERENCE}/src not found: this generator only runs in the build container")
+    absent = install_placeholders()
+    sys.path.insert(0, REFERENCE)
+    sys.dont_write_bytecode = True  # /root/reference is read-only; leave it untouched
+    gu = importlib.import_module("src.utils.graphic_utils")
+    mu = importlib.import_module("src.utils.math_utils")
+    tr = importlib.import_module("src.models.transformers")
+    tan = importlib.import_module("src.models.triplane_audio_net")
+    sd_mod = importlib.import_module("src.models.smplx_decoder")
+    rd = importlib.import_module("src.models.renderer")
+    for m in (gu, mu, tr, tan, sd_mod, rd):
+        assert os.path.realpath(m.__file__).startswith(os.path.realpath(REFERENCE)), m.__file__
+    PHASE["name"] = "run"
+    torch.manual_seed(0)
+    torch.set_num_threads(1)  # bit-reproducible sums
+    entries = [fixture_camera(gu), fixture_reducers(tan), fixture_feedforward(tr), fixture_triplane(rd, mu),
+               fixture_audio_net(tan, tr), fixture_smplx_decoder(sd_mod)]
+    assert not RUN_EVENTS, f"a placeholder was used while producing fixtures: {RUN_EVENTS}"
+    manifest = {"generator": "tests/golden/make_reference_golden.py", "reference": REFERENCE, "torch": torch.__version__,
+                "absent_packages_mapped_to_inert_placeholders": absent,
+                "placeholder_events_during_import": sorted(set(f"{a}: {b}" for a, b in IMPORT_EVENTS)),
+                "placeholder_uses_during_run": len(RUN_EVENTS), "fixtures": entries}
+    with open(os.path.join(HERE, "ref_manifest.json"), "w") as fh:
+        json.dump(manifest, fh, indent=1, sort_keys=True)
+    for e in entries:
+        print(f"{e['file']:28s} tier {e['tier']}  {e['bytes']:8d} B")
+    print("placeholder uses in the run phase:", len(RUN_EVENTS))
+
+
+if __name__ == "__main__":
+    main()

@@ -49,8 +49,48 @@ def test_token_generation_matches_oracle():
                                                        num_layers=2, heads=2)
     assert got_tri.shape == (B, 3, 32, 192) and got_smpl.shape == (B, 3, 32, 10)
     scale = ref_tri.abs().max().item()
-    assert (got_tri.cpu() - ref_tri).abs().max() <= 2e-4 * max(1.0, scale)
-    assert (got_smpl.cpu() - ref_smpl).abs().max() <= 2e-4 * max(1.0, scale)
+    assert (got_tri.cpu() - ref_tri).abs().max() <= 2e-5 * max(1.0, scale)
+    assert (got_smpl.cpu() - ref_smpl).abs().max() <= 2e-5 * max(1.0, scale)
+
+
+def test_full_size_net_two_autoregressive_steps_match_the_oracle_in_fp32_and_fp64():
+    """the FULL-SIZE AudioTriplaneNet (8 layers, 512 wide, 8 x 64 heads, S = 6304, B = 1) for two
+    autoregressive steps on the HIP path against oracle.transformer.audio_triplane_tokens evaluated on the CPU in
+    fp32 AND fp64 (same weights).  The second step consumes the first one's tokens, so feedback is exercised.
+
+    Tolerance: tokens are O(1) (N(0,1) inputs + the transformer's residual output).  Against the fp64 evaluation the
+    HIP path must be within 1e-5 * scale and no worse than 3x the CPU fp32 evaluation's own distance from fp64 (+
+    1e-6 * scale slack): i.e. it is an fp32 evaluation of the same function, not merely "close"."""
+    from audio_motion_avatar_amd.config import ModelConfig
+    from audio_motion_avatar_amd.triplane_audio_net import AudioTriplaneNet
+    from oracle import transformer as o_tr
+
+    torch.set_num_threads(max(1, min(16, len(__import__("os").sched_getaffinity(0)))))
+    net = AudioTriplaneNet(ModelConfig(), renderer=None).eval()
+    randomize(net, 11)
+    params = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    g = torch.Generator().manual_seed(12)
+    audio = torch.randn(1, 2, 768, generator=g)
+    tri = torch.randn(1, 2, 256, 3 * 32 * 32, generator=g)
+    smpl = torch.randn(1, 2, 256, 80, generator=g)
+    net = net.cuda()
+    with torch.no_grad():
+        got_tri, got_smpl = net.generate_tokens(audio.cuda(), tri.cuda(), smpl.cuda(), num_steps=2)
+        got = torch.cat([got_tri, got_smpl], dim=-1).cpu()
+        r32 = torch.cat(o_tr.audio_triplane_tokens(params, audio, tri, smpl, t_output=2), dim=-1)
+        p64 = {k: v.double() for k, v in params.items()}
+        r64 = torch.cat(o_tr.audio_triplane_tokens(p64, audio.double(), tri.double(), smpl.double(), t_output=2), dim=-1)
+    assert got.shape == (1, 2, 256, 3072 + 80)
+    scale = float(r64.abs().max())
+    e_hip = [float((got[:, t].double() - r64[:, t]).abs().max()) for t in range(2)]
+    e_cpu = [float((r32[:, t].double() - r64[:, t]).abs().max()) for t in range(2)]
+    e_32 = float((got - r32).abs().max())
+    print(f"full-size net: scale {scale:.3f}; |hip - fp64| per step {e_hip}; |cpu fp32 - fp64| per step {e_cpu}; "
+          f"|hip - cpu fp32| {e_32:.3e}")
+    assert scale > 1.0 and float((r64[:, 1] - r64[:, 0]).abs().max()) > 1e-2  # the steps differ: feedback is live
+    for t in range(2):
+        assert e_hip[t] <= 1e-5 * scale, (t, e_hip, scale)
+        assert e_hip[t] <= 3.0 * e_cpu[t] + 1e-6 * scale, (t, e_hip, e_cpu)
 
 
 def test_forward_returns_the_reference_five_tuple():

@@ -1,4 +1,5 @@
 """The HIP kernels (through the C ABI) against the committed golden fixtures (fp64 oracle results, tests/golden/)."""
+import math
 import os
 
 import numpy as np
@@ -143,3 +144,56 @@ def test_triplane_upsampler_path_matches_oracle():
     for k in ("xyz", "scale", "rot", "opacity", "color"):
         assert (gaussians[k].cpu() - g[k]).abs().max() <= 1e-4, k
     assert images.shape == (1, F_, 64, 64, 3)
+
+
+def test_smplx_decoder_on_the_device_matches_the_oracle_directly():
+    """A4 on the GPU, directly: the device SMPLXDecoder's parameters against
+    oracle.smplx_decoder_forward at the reference size (256 x 80 tokens), and the rot6d -> axis-angle conversion at
+    rotations of exactly 0, nearly 0, nearly pi and exactly pi.  Axis-angle is compared directly where it is well
+    conditioned (angle < 3) and through the rotation it encodes (Rodrigues, what LBS consumes) everywhere."""
+    from audio_motion_avatar_amd.config import RendererConfig
+    from audio_motion_avatar_amd.smplx_decoder import SMPLXDecoder, matrix_to_axis_angle, rotation_6d_to_matrix
+    from oracle import rotation as o_rot
+    from oracle.lbs import batch_rodrigues
+    from oracle.smplx_decoder import smplx_decoder_forward
+
+    torch.manual_seed(3)
+    cfg = RendererConfig()
+    dec = SMPLXDecoder(cfg).eval()
+    with torch.no_grad():
+        for m in (dec.dec_body_pose, dec.dec_hand_pose, dec.dec_body_root_pose):
+            m.weight.mul_(6.0)  # spread the rotations over the whole range
+    params = {"smpl_decoder." + k: v.detach().clone() for k, v in dec.state_dict().items()}
+    tokens = torch.randn(7, 256, 80)
+    with torch.no_grad():
+        got = dec.cuda()(tokens.cuda())
+    want = smplx_decoder_forward(params, tokens)
+    assert set(got) == set(want)
+    worst = 0.0
+    for k, w in want.items():
+        g = got[k].cpu()
+        assert g.shape == w.shape, (k, g.shape, w.shape)
+        if k in ("betas", "transl", "expression"):
+            assert (g - w).abs().max() <= 1e-5, k
+            continue
+        ang = w.reshape(-1, 3).norm(dim=-1)
+        ok = ang < 3.0
+        assert ok.float().mean() > 0.5
+        assert (g.reshape(-1, 3)[ok] - w.reshape(-1, 3)[ok]).abs().max() <= 2e-5, k
+        r_err = (batch_rodrigues(g.reshape(-1, 3)) - batch_rodrigues(w.reshape(-1, 3))).abs().max().item()
+        worst = max(worst, r_err)
+        assert r_err <= 1e-5, (k, r_err)
+    # the conversion alone at the hard angles, about the coordinate axes and random axes
+    g_ = torch.Generator().manual_seed(5)
+    axes = torch.cat([torch.eye(3), torch.nn.functional.normalize(torch.randn(13, 3, generator=g_), dim=-1)])
+    angles = torch.tensor([0.0, 1e-7, 1e-4, 0.5, 3.0, math.pi - 1e-3, math.pi - 1e-5, math.pi])
+    aa = (axes[:, None, :] * angles[None, :, None]).reshape(-1, 3)
+    R = batch_rodrigues(aa.double()).float()                   # [n,3,3]
+    d6 = R[:, :2, :].reshape(-1, 6) * torch.linspace(0.5, 2.0, R.shape[0])[:, None]  # rows, arbitrary positive length
+    got_aa = matrix_to_axis_angle(rotation_6d_to_matrix(d6.cuda())).cpu()
+    want_aa = o_rot.matrix_to_axis_angle(o_rot.rotation_6d_to_matrix(d6))
+    assert torch.isfinite(got_aa).all()
+    assert (batch_rodrigues(got_aa) - batch_rodrigues(want_aa)).abs().max() <= 1e-5
+    assert (batch_rodrigues(got_aa) - R).abs().max() <= 2e-4  # and both encode the rotation they were built from
+    small = angles.repeat(axes.shape[0]) < 3.05
+    assert (got_aa[small] - want_aa[small]).abs().max() <= 2e-5

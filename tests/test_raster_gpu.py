@@ -3,8 +3,11 @@
 Tolerance (BASELINE.json north_star): RGB / alpha max-abs <= 1e-3 against the fp32 oracle.  The algorithm itself is
 discontinuous (skip when alpha < 1/255, stop when T' < 1e-4, skip when power > 0), so two correct fp32
 implementations can take different branches where a value sits within rounding of a threshold.  The oracle flags
-those pixels (`unstable`: a decision within 1e-4 relative of a threshold).  The test holds
-    * every stable pixel to 1e-3 (measured differences are ~1e-6),
+those pixels (`unstable`: a decision within 1e-4 relative of a threshold).  Every comparison
+prints (and logs to gpurun_out/raster_parity.jsonl) the maximum over ALL pixels, the number of pixels above 1e-3 and
+the number flagged, and holds
+    * every unflagged pixel to 1e-3 (measured differences are ~1e-6),
+    * the number of pixels above 1e-3 to at most the number flagged,
     * every flagged pixel to one flipped decision (<= 1.2e-2), and
     * the flagged set to < 0.5 % of the image,
 while geometry decisions (radii, tile rectangles, depth order, instance counts) must match exactly: the HIP
@@ -33,18 +36,42 @@ def run_hip(scene, **kw):
     return out
 
 
+def report(test, frame, name, diff, unstable, tol=TOL):
+    """All-pixel statistics of one comparison (printed, and appended to gpurun_out/raster_parity.jsonl when that
+    directory exists): maximum over ALL pixels, pixels above the tolerance, pixels the oracle flags as sitting on one
+    of the algorithm's discontinuities.  Fails when an UNFLAGGED pixel is off by more than the tolerance, when more
+    pixels are off than were flagged, or when a flagged pixel is off by more than one flipped decision."""
+    import json
+    import os
+
+    above = diff > tol
+    rec = {"test": test, "frame": int(frame), "what": name, "pixels": int(diff.size), "max_abs_all_pixels": float(diff.max()),
+           "max_abs_unflagged": float((diff * ~unstable).max()), "pixels_above_tol": int(above.sum()),
+           "unflagged_above_tol": int((above & ~unstable).sum()), "pixels_flagged": int(unstable.sum()), "tol": tol}
+    print("raster parity:", json.dumps(rec))
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "raster_parity.jsonl"), "a") as fh:
+            fh.write(json.dumps(rec) + "\n")
+    assert rec["unflagged_above_tol"] == 0, f"{name}: unflagged pixels off by {rec['max_abs_unflagged']}"
+    assert rec["pixels_above_tol"] <= rec["pixels_flagged"], f"{name}: {rec['pixels_above_tol']} pixels off, {rec['pixels_flagged']} flagged"
+    assert rec["max_abs_all_pixels"] <= FLIP_TOL, f"{name}: flagged pixels off by {rec['max_abs_all_pixels']}"
+    return rec
+
+
 def compare(scene, out, tol=TOL, **settings):
+    import inspect
+
+    test = next((fr.function for fr in inspect.stack() if fr.function.startswith("test_")), "?")
     ref = oracle_frames(scene, np.float32, **settings)
     rgba = out["rgba"].cpu().numpy()
     for f, r in enumerate(ref):
         got_rgb = np.moveaxis(rgba[f, :, :, :3], -1, 0)
-        stable = r["unstable"] == 0
-        assert stable.mean() > 0.995, f"frame {f}: {1 - stable.mean():.4%} of the pixels sit on a threshold"
-        for name, got, want in (("rgb", got_rgb, r["color"]), ("alpha", rgba[f, :, :, 3], r["alpha"]),
-                                ("inv_depth", out["inv_depth"][f].cpu().numpy(), r["inv_depth"])):
-            diff = np.abs(got - want)
-            assert (diff * stable).max() <= tol, f"frame {f} {name}: stable pixels off by {(diff * stable).max()}"
-            assert diff.max() <= FLIP_TOL, f"frame {f} {name}: flagged pixels off by {diff.max()}"
+        unstable = r["unstable"] != 0
+        assert unstable.mean() < 0.005, f"frame {f}: {unstable.mean():.4%} of the pixels sit on a threshold"
+        report(test, f, "rgb", np.abs(got_rgb - r["color"]).max(axis=0), unstable, tol)
+        report(test, f, "alpha", np.abs(rgba[f, :, :, 3] - r["alpha"]), unstable, tol)
+        report(test, f, "inv_depth", np.abs(out["inv_depth"][f].cpu().numpy() - r["inv_depth"]), unstable, tol)
         assert np.array_equal(out["radii"][f].cpu().numpy(), r["radii"]), f"frame {f} radii"
     total, over = out["workspace"].status()
     assert not over
@@ -127,14 +154,15 @@ def test_activations_and_clamp_match_render_one():
     K = torch.tensor([[[96.0, 0, 48], [0, 96.0, 48], [0, 0, 1]]])
     E = torch.eye(4)[None]
     ref, ref_alpha, unstable = orc.render_batch(gauss, K[None], E[None], (H, W), full=True)
-    stable = ~unstable[0, 0]
     view, proj, tanfov, _ = ops.camera_from_intrinsics(K.cuda(), E.cuda(), H, W)
     out = ops.rasterize(*[gauss[k].cuda() for k in ("xyz", "rot", "scale", "opacity", "color")], view, proj, tanfov,
                         H, W, apply_activations=True, clamp_output=True)
     rgba = out["rgba"].cpu()
-    assert ((rgba[0, :, :, :3] - ref[0, 0]).abs() * stable[..., None]).max() <= TOL
-    assert ((rgba[0, :, :, 3] - ref_alpha[0, 0]).abs() * stable).max() <= TOL
-    assert (rgba[0, :, :, :3] - ref[0, 0]).abs().max() <= FLIP_TOL
+    flagged = unstable[0, 0].numpy()
+    report("test_activations_and_clamp_match_render_one", 0, "rgb",
+           (rgba[0, :, :, :3] - ref[0, 0]).abs().amax(-1).numpy(), flagged)
+    report("test_activations_and_clamp_match_render_one", 0, "alpha", (rgba[0, :, :, 3] - ref_alpha[0, 0]).abs().numpy(),
+           flagged)
 
 
 def test_stress_config_one_frame():
@@ -157,6 +185,6 @@ def test_full_ted_frame_runs():
     out = run_hip(scene)
     ref = oracle_frames(scene, np.float32)[0]
     rgba = out["rgba"].cpu().numpy()[0]
-    stable = ref["unstable"] == 0
-    assert (np.abs(np.moveaxis(rgba[..., :3], -1, 0) - ref["color"]) * stable).max() <= TOL
+    report("test_full_ted_frame_runs", 0, "rgb", np.abs(np.moveaxis(rgba[..., :3], -1, 0) - ref["color"]).max(axis=0),
+           ref["unstable"] != 0)
     assert np.array_equal(out["radii"][0].cpu().numpy(), ref["radii"])
