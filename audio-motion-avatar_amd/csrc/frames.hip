@@ -260,6 +260,84 @@ __global__ __launch_bounds__(256) void tile_unpack_rows_kernel(int F, int gx, in
     }
 }
 
+// Differential form of the unpack.  The dense output buffer is REUSED from step to step (the exchange double-buffers
+// two of them) and ~80 % of an avatar frame is background, so most tiles already hold what this step would write.
+// `state` remembers per output tile what the buffer holds: the background word 0x00BBGGRR it was cleared to, or -1
+// ("holds rendered pixels" / unknown; a fresh buffer starts as all -1).  A tile is written when it is stored on the
+// wire (payload copy) or when it is background now but the buffer does not hold this background yet (clear); every
+// other tile is skipped.  Bytes written per step drop from the dense 786 KB per frame to the stored tiles (+ the few
+// tiles the body moved out of).
+// grid = (frames, buffers); block = 256 threads = 4 waves, wave w walks tile rows w, w + 4, ...; a tile row's
+// selected tiles are written row by row of 16 pixels (48 B = three 16-byte chunks per tile, neighbouring tiles adjoin).
+__global__ __launch_bounds__(256) void tile_unpack_delta_kernel(int F, int gx, int T, int H, int W, int cap,
+                                                                const unsigned char *__restrict__ wire,
+                                                                size_t wire_stride, unsigned char *__restrict__ out,
+                                                                int *__restrict__ state, int *__restrict__ status) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    extern __shared__ int delta_lds[];  // [T] source: slot >= 0, -1 = clear to background, -2 = skip; then 4 x 128 ints of per-wave lists
+    const int f = blockIdx.x, b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned char *buf = wire + (size_t)b * wire_stride;
+    const int *header = reinterpret_cast<const int *>(buf);
+    const unsigned char *payload = buf + ((size_t)(kWireHeaderInts + F + F * T) * 4 + 15) / 16 * 16;
+    if (f == 0 && threadIdx.x == 0 && (header[0] != kWireMagic || header[1] > cap)) atomicOr(status, 1);
+    const int bgw = header[7] & 0x00ffffff;
+    const int *offsets = header + kWireHeaderInts + F + f * T;
+    int *st = state + ((size_t)b * F + f) * T;
+    for (int t = threadIdx.x; t < T; t += blockDim.x) {
+        const int off = offsets[t], had = st[t];
+        int src = -2;
+        if (off >= 0 && off < cap)
+            src = off, st[t] = -1;
+        else if (had != bgw)
+            src = -1, st[t] = bgw;
+        delta_lds[t] = src;
+    }
+    __syncthreads();
+    const unsigned ch[3] = {(unsigned)bgw & 255u, ((unsigned)bgw >> 8) & 255u, ((unsigned)bgw >> 16) & 255u};
+    u32x4 bgv[3];  // background chunk by position inside a tile row: byte n of chunk `part` is channel (16 part + n) % 3
+#pragma unroll
+    for (int part = 0; part < 3; ++part)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int n0 = 16 * part + 4 * k;
+            bgv[part][k] = ch[n0 % 3] | (ch[(n0 + 1) % 3] << 8) | (ch[(n0 + 2) % 3] << 16) | (ch[(n0 + 3) % 3] << 24);
+        }
+    const int gy = T / gx;
+    unsigned char *frame = out + ((size_t)b * F + f) * H * W * 3;
+    for (int ty = wave; ty < gy; ty += 4) {
+        const int rows = min(16, H - ty * 16);
+        // the row's tiles that need a write, compacted (gx <= 64: one ballot; wider rows in rounds of 64)
+        for (int tx0 = 0; tx0 < gx; tx0 += 64) {
+            const int tx = tx0 + lane;
+            const int src = tx < gx ? delta_lds[ty * gx + tx] : -2;
+            const unsigned long long live = __ballot(src != -2);
+            const int n = __popcll(live);
+            if (n == 0) continue;
+            // compact (tile column, source) of the selected tiles into this wave's list
+            int *list = delta_lds + T + wave * 128;
+            if (src != -2) {
+                const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(live >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)live, 0));
+                list[2 * pos] = tx, list[2 * pos + 1] = src;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // item k: pixel row r = k / (3 n), entry j = (k % (3 n)) / 3, 16-byte part k % 3 of the tile's 48-byte row
+            const int per_row = 3 * n;
+            for (int k = lane; k < rows * per_row; k += 64) {
+                const int r = k / per_row, rem = k - r * per_row;
+                const int j = rem / 3, part = rem - 3 * j;
+                const int txs = list[2 * j], s2 = list[2 * j + 1];
+                u32x4 v = part == 0 ? bgv[0] : (part == 1 ? bgv[1] : bgv[2]);
+                if (s2 >= 0) v = *reinterpret_cast<const u32x4 *>(payload + (size_t)s2 * kTileBytes + r * 48 + part * 16);
+                *reinterpret_cast<u32x4 *>(frame + ((size_t)(ty * 16 + r) * W + txs * 16) * 3 + part * 16) = v;
+            }
+            __builtin_amdgcn_wave_barrier();  // the list is rewritten by the next round
+        }
+    }
+}
+
 static size_t wire_payload_at(int F, int tiles) { return ((size_t)(kWireHeaderInts + F + tiles) * 4 + 15) / 16 * 16; }
 
 }  // namespace amav
@@ -335,6 +413,27 @@ extern "C" int amav_frames_unpack_tiles(int num_buffers, int F, int H, int W, in
         num_buffers, tiles, gx, T, H, W, (int)cap_tiles, static_cast<const unsigned char *>(wire_all), wire_stride,
         out_rgb8, status);
     return check_launch("amav_frames_unpack_tiles");
+}
+
+extern "C" int amav_frames_unpack_tiles_delta(int num_buffers, int F, int H, int W, int64_t cap_tiles,
+                                              const void *wire_all, size_t wire_stride, uint8_t *out_rgb8,
+                                              int32_t *tile_state, int32_t *status, void *stream_) {
+    AMAV_REQUIRE(num_buffers > 0 && F > 0 && H > 0 && W > 0 && cap_tiles >= 0, "amav_frames_unpack_tiles_delta: bad sizes");
+    AMAV_REQUIRE(wire_all && out_rgb8 && status && tile_state, "amav_frames_unpack_tiles_delta: NULL pointer");
+    const size_t need = amav_frames_wire_bytes(F, H, W, cap_tiles);
+    AMAV_REQUIRE(need != 0 && wire_stride >= need && wire_stride % 16 == 0,
+                 "amav_frames_unpack_tiles_delta: wire stride %zu does not hold a %zu-byte buffer", wire_stride, need);
+    AMAV_REQUIRE(W % 16 == 0, "amav_frames_unpack_tiles_delta: width %d is not a multiple of 16 (use amav_frames_unpack_tiles)", W);
+    AMAV_REQUIRE((reinterpret_cast<uintptr_t>(wire_all) & 15) == 0 && (reinterpret_cast<uintptr_t>(out_rgb8) & 15) == 0,
+                 "amav_frames_unpack_tiles_delta: misaligned buffer");
+    AMAV_REQUIRE(F <= 65535 * 32768 && num_buffers <= 65535, "amav_frames_unpack_tiles_delta: grid too large");
+    const int gx = W / 16, T = gx * ((H + 15) / 16);
+    AMAV_REQUIRE(((size_t)T + 512) * sizeof(int) <= 64 * 1024, "amav_frames_unpack_tiles_delta: %d tiles per frame exceed the LDS table", T);
+    const dim3 grid((unsigned)F, (unsigned)num_buffers);
+    tile_unpack_delta_kernel<<<grid, 256, ((size_t)T + 4 * 128) * sizeof(int), static_cast<hipStream_t>(stream_)>>>(
+        F, gx, T, H, W, (int)cap_tiles, static_cast<const unsigned char *>(wire_all), wire_stride, out_rgb8, tile_state,
+        status);
+    return check_launch("amav_frames_unpack_tiles_delta");
 }
 
 extern "C" int amav_frames_to_rgb8(int64_t num_pixels, const float *rgba, uint8_t *out_rgb8, void *stream) {

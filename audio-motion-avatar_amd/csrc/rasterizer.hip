@@ -26,6 +26,7 @@
 //                  store instruction writes eight full 128-byte lines.  Tiles reach the waves through eight work
 //                  queues (one per XCD: tile-row bands, rotating with the frame) bucketed by list length and
 //                  dispatched longest first.
+#include <algorithm>
 #include <cstdlib>
 
 #include "amav_common.h"
@@ -33,8 +34,11 @@
 namespace amav {
 namespace raster {
 
+#ifndef AMAV_ABLATE
+#define AMAV_ABLATE 0  /* diagnostic builds of the blend kernel only (tools/): never set in the product */
+#endif
 constexpr int kTile = AMAV_TILE;
-constexpr int kRenderWaves = 1;    // waves (= tiles) per blend workgroup
+constexpr int kRenderWavesPerSimd = 5;  // blend kernel: one-wave workgroups resident per SIMD (register cap)
 constexpr int kSortCap = 512;      // keys a wave sorts in its LDS slice (4 KiB); longer lists go to sort_big
 constexpr int kBigLdsCap = 2048;   // keys a sort_big block sorts in LDS (16 KiB); longer lists are sorted in place
 constexpr int kBigBlocks = 1280;
@@ -54,6 +58,10 @@ struct Status {
     // work lists of the blend kernel: per XCD queue, bucketed by list length (bucket 0 = longest)
     int qcount[kQueues][kBuckets];
     int nempty;           // tiles without Gaussians (background fill)
+    // blend kernel: next position of each queue that no wave has taken yet (beyond the first round).  One 128-byte line
+    // per queue: device-scope atomics are executed at the memory side line by line, so cursors sharing a line would
+    // serialise all eight queues (measured: 1.23 ms instead of 0.6 for the kernel)
+    int next[kQueues][32];
 };
 
 struct Buffers {
@@ -582,7 +590,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct WaveLds {
     unsigned long long keys[kSortCap];  // keys, then (in place) the blend order as 32-bit Gaussian ids
-    float4 stage[3][64];
+    float4 stage[3][65];                // staged records {x, y, A', B'} {C', opacity, r, g} {b, 1/depth, ..}; [64] = null record
 };
 
 // Rank sort of n <= 64 * KPL unique keys held in LDS: rank = number of smaller keys, no cross-lane exchange.  The
@@ -764,21 +772,93 @@ __device__ __forceinline__ void wave_bitonic_sort(unsigned long long *a, unsigne
 // One pixel, one Gaussian.  T > 0: live transmittance; T < 0: pixel finished, |T| is its final transmittance.
 // A finished pixel needs no test of its own: with T < 0 the weight alpha*T is negative, T - alpha*T < 1e-4 holds, so
 // the Gaussian is either invalid (w = 0) or takes the "finished" branch (w = 0, T <- -|T| = T).
+// Record words: a = {x, y, A', B'}, b = {C', opacity, r, g}, c = {b, 1/depth}; A' B' C' are the coefficients of
+// log2(alpha / opacity) = A' dx^2 + B' dx dy + C' dy^2 (bin_kernel), evaluated as dx (A' dx + B' dy) + (C' dy) dy.
 template <bool kInvDepth>
-__device__ __forceinline__ void blend_px(float power2, float op, float cr, float cg, float cb, float invd, float &T,
-                                         float &Cr, float &Cg, float &Cb, float &Dp) {
-    const float alpha = fminf(0.99f, op * __builtin_amdgcn_exp2f(power2));
+__device__ __forceinline__ void blend_px(const float4 &a, const float4 &b, const float2 &c, float px, float py,
+                                         float &T, float &Cr, float &Cg, float &Cb, float &Dp) {
+    const float dx = a.x - px, dy = a.y - py;
+    const float power2 = fmaf(dx, fmaf(a.w, dy, a.z * dx), (b.x * dy) * dy);
+#if AMAV_ABLATE == 2  /* diagnostic build: no transcendental */
+    float alpha = fminf(0.99f, b.y * (power2 + 1.0f));
+#else
+    float alpha = fminf(0.99f, b.y * __builtin_amdgcn_exp2f(power2));
+#endif
+    // The three decisions of the reference (skip power > 0, skip alpha < 1/255, stop at T' < 1e-4) as compare + select
+    // pairs on VCC only: no SGPR-pair logic between vector instructions (each v_cmp -> s_and -> v_cndmask round trip
+    // parks the wave until the vector pipe has drained).
+    alpha = power2 <= 0.0f ? alpha : 0.0f;
+    alpha = alpha >= (1.0f / 255.0f) ? alpha : 0.0f;  // 0: this Gaussian does not touch the pixel
     const float w0 = alpha * T;
-    const float test_T = T - w0;  // = T (1 - alpha) up to one rounding
-    const bool valid = (power2 <= 0.0f) & (alpha >= (1.0f / 255.0f));
-    const bool fin = valid & (test_T < 0.0001f);
-    const float w = (valid & !fin) ? w0 : 0.0f;
-    Cr = fmaf(cr, w, Cr);
-    Cg = fmaf(cg, w, Cg);
-    Cb = fmaf(cb, w, Cb);
-    if (kInvDepth) Dp = fmaf(invd, w, Dp);
+    const float test_T = T - w0;       // = T (1 - alpha) up to one rounding; = T when alpha was zeroed
+    // A live pixel has T >= 1e-4 (it would have finished otherwise), so with alpha = 0 the test below is false; a
+    // finished pixel (T < 0) gives test_T < 0 and re-takes the "finished" branch, which leaves it as it is.
+    const bool fin = test_T < 0.0001f;
+    const float w = fin ? 0.0f : w0;
+    Cr = fmaf(b.z, w, Cr);
+    Cg = fmaf(b.w, w, Cg);
+    Cb = fmaf(c.x, w, Cb);
+    if (kInvDepth) Dp = fmaf(c.y, w, Dp);
     T -= w;                    // unchanged unless this Gaussian was blended
     T = fin ? -fabsf(T) : T;   // finished: the saturating Gaussian is not blended, the sign marks the pixel done
+}
+
+struct StageRec {
+    float4 a, b;
+    float2 c;
+};
+
+__device__ __forceinline__ StageRec read_stage(const WaveLds &L, int j) {  // j is wave-uniform: broadcast reads
+    StageRec r;
+    r.a = L.stage[0][j];
+    r.b = L.stage[1][j];
+    r.c = *reinterpret_cast<const float2 *>(&L.stage[2][j]);
+    return r;
+}
+
+constexpr int kNullSlot = 64;  // staging slot of a record with opacity 0: what an exhausted list keeps reading
+
+// Next set bit of a wave-uniform mask, cleared, in three scalar instructions; an exhausted mask yields kNullSlot, so
+// the caller's LDS reads stay unconditional and the compiler can count them exactly in its s_waitcnt (a read under a
+// branch makes every later wait assume the worst: "everything issued so far").
+__device__ __forceinline__ int next_bit(unsigned long long &mask) {
+    int j;
+    asm("s_ff1_i32_b64 %0, %1\n\ts_bitset0_b64 %1, %0\n\ts_min_u32 %0, %0, %2" : "=&s"(j), "+s"(mask) : "n"(kNullSlot) : "scc");
+    return j;  // s_ff1 of 0 is -1: bit 63 of the (empty) mask is "cleared" and the unsigned minimum gives 64
+}
+
+// One 8x8 quadrant of the tile (one pixel per lane) against the staged Gaussians whose bit is set in `mask` (a
+// wave-uniform 64-bit ballot, i.e. scalar registers: the loop walks its set bits with scalar instructions, lowest =
+// nearest first, so the blend order is the staged order).  Records are read from LDS two Gaussians ahead of their use
+// (three register sets, loop unrolled by three so no set is ever copied); the list is processed in threes, the last
+// group padded with the null record, so there is one loop branch per three Gaussians.  Returns false when every
+// pixel of the quadrant has finished (checked every six Gaussians).
+template <bool kInvDepth>
+__device__ __forceinline__ bool blend_quadrant(unsigned long long mask, const WaveLds &L, float px, float py, float &T,
+                                               float &R, float &G, float &B, float &D) {
+    int groups = (__popcll(mask) + 2) / 3;  // >= 1
+    StageRec r0 = read_stage(L, next_bit(mask));
+    StageRec r1 = read_stage(L, next_bit(mask)), r2;
+    for (;;) {
+#if AMAV_ABLATE == 1  /* diagnostic build: no LDS reads inside the loop */
+        (void)next_bit(mask); (void)next_bit(mask); (void)next_bit(mask);
+        r2 = r0;
+        asm volatile("" : "+v"(r0.a.x), "+v"(r1.a.x), "+v"(r2.a.x));
+        blend_px<kInvDepth>(r0.a, r0.b, r0.c, px, py, T, R, G, B, D);
+        blend_px<kInvDepth>(r1.a, r1.b, r1.c, px, py, T, R, G, B, D);
+        blend_px<kInvDepth>(r2.a, r2.b, r2.c, px, py, T, R, G, B, D);
+#else
+        r2 = read_stage(L, next_bit(mask));
+        blend_px<kInvDepth>(r0.a, r0.b, r0.c, px, py, T, R, G, B, D);
+        r0 = read_stage(L, next_bit(mask));
+        blend_px<kInvDepth>(r1.a, r1.b, r1.c, px, py, T, R, G, B, D);
+        r1 = read_stage(L, next_bit(mask));
+        blend_px<kInvDepth>(r2.a, r2.b, r2.c, px, py, T, R, G, B, D);
+#endif
+        if (--groups == 0) break;
+        if ((groups & 1) == 0 && !__any(T > 0.f)) return false;  // a finished quadrant takes no further Gaussians
+    }
+    return __any(T > 0.f);
 }
 
 #define AMAV_STAMP(slot)                                                                              \
@@ -822,7 +902,6 @@ __device__ __forceinline__ void render_tile(const Params &p, WaveLds &L, int ite
     float pxf0 = (float)(X0 + lx), pxf1 = (float)(X0 + 8 + lx);
     float pyf0 = (float)(Y0 + ly), pyf1 = (float)(Y0 + 8 + ly);
     asm volatile("" : "+v"(pxf0), "+v"(pxf1), "+v"(pyf0), "+v"(pyf1));  // keep them in registers (no re-convert)
-    const f32x2 pxp = {pxf0, pxf1}, pyp = {pyf0, pyf1};
     const bool in0 = X0 + lx < p.W, in1 = X0 + 8 + lx < p.W, inr0 = Y0 + ly < p.H, inr1 = Y0 + 8 + ly < p.H;
 
     float T0 = (in0 & inr0) ? 1.f : -1.f, T1 = (in1 & inr0) ? 1.f : -1.f;
@@ -840,6 +919,12 @@ __device__ __forceinline__ void render_tile(const Params &p, WaveLds &L, int ite
         const unsigned *order_g = p.buf.sorted + (size_t)f * p.cap_per_frame + beg;  // long lists only
         unsigned *order_l = reinterpret_cast<unsigned *>(L.keys);
         const bool local = n <= kSortCap;
+#if AMAV_ABLATE == 4 || AMAV_ABLATE == 8
+        if (local) {
+            for (int k = lane; k < n; k += 64) order_l[k] = (unsigned)keys[k];
+            wave_sync();
+        } else
+#endif
         if (local) {
             unsigned *cnt = reinterpret_cast<unsigned *>(L.stage);  // the staging buffers are idle while sorting
             bool done = false;
@@ -870,15 +955,27 @@ __device__ __forceinline__ void render_tile(const Params &p, WaveLds &L, int ite
             }
         }
         AMAV_STAMP(2);
+        // the sorts used the staging buffers as scratch: (re)write the null record (opacity 0 blends nothing)
+        if (lane < 3) L.stage[lane][kNullSlot] = make_float4(0.f, 0.f, 0.f, 0.f);
 
         // ---- blend, 64 Gaussians per staging round
         const float4 *geom = p.buf.geom + (size_t)f * p.N * 3;
         float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0, g2 = g0;
-        if (lane < n) {
-            const unsigned id = local ? order_l[lane] : order_g[lane];
+        // blend order of position k: from this wave's LDS slice, or (lists longer than kSortCap) from sort_big's output.
+        // Two explicit paths: a select between an LDS and a global pointer becomes a FLAT load, whose completion the
+        // hardware can only express as "everything done" (vmcnt(0) + lgkmcnt(0)).
+        typedef __attribute__((address_space(3))) const unsigned lds_u32;
+        lds_u32 *order_lds = (lds_u32 *)order_l;
+        auto load_records = [&](int k) {
+            unsigned id;
+            if (local)
+                id = order_lds[k];
+            else
+                id = order_g[k];
             const float4 *g = geom + (size_t)id * 3;
             g0 = g[0], g1 = g[1], g2 = g[2];
-        }
+        };
+        if (lane < n) load_records(lane);
         const float X0f = (float)X0, Y0f = (float)Y0;
         int qalive = 15;  // quadrants that still have an unfinished pixel (wave-uniform)
         for (int base = 0; qalive && base < n; base += 64) {
@@ -892,49 +989,26 @@ __device__ __forceinline__ void render_tile(const Params &p, WaveLds &L, int ite
                 qm = (int)(hx0 & hy0) | ((int)(hx1 & hy0) << 1) | ((int)(hx0 & hy1) << 2) | ((int)(hx1 & hy1) << 3);
                 qm &= qalive;
             }
-            const unsigned long long hit = __ballot(qm != 0);
-            const int cnt = __popcll(hit);
+            // every lane stages its record at its own (= sorted) position; the four ballots are the quadrants' lists
             if (qm != 0) {
-                const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(hit >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hit, 0));
-                L.stage[0][pos] = g0;
-                L.stage[1][pos] = g1;
-                L.stage[2][pos] = make_float4(g2.x, g2.y, __int_as_float(qm), 0.f);
+                L.stage[0][lane] = g0;
+                L.stage[1][lane] = g1;
+                L.stage[2][lane] = g2;  // {b, 1/depth, box half extents}: stored whole, so no copy of it is made early
             }
+            const unsigned long long m0 = __ballot(qm & 1), m1 = __ballot(qm & 2), m2 = __ballot(qm & 4),
+                                     m3 = __ballot(qm & 8);
             wave_sync();
             // prefetch the next round's records while this one is blended
-            if (base + 64 + lane < n) {
-                const unsigned id = local ? order_l[base + 64 + lane] : order_g[base + 64 + lane];
-                const float4 *g = geom + (size_t)id * 3;
-                g0 = g[0], g1 = g[1], g2 = g[2];
-            }
-            // software pipeline, unrolled by two so the prefetched record needs no register moves: record j+1 is read
-            // from LDS while record j is blended
-            auto blend = [&](const float4 &a, const float4 &bq, const float4 &c) {
-                const int m = __builtin_amdgcn_readfirstlane(__float_as_int(c.z)) & qalive;
-                if (m) {
-                    // the two columns / two rows of this lane's pixels as packed fp32 pairs
-                    const f32x2 dx = a.x - pxp, dy = a.y - pyp;
-                    const f32x2 ax = (a.z * dx) * dx, cy = (bq.x * dy) * dy, bx = a.w * dx;
-                    if (m & 1) blend_px<kInvDepth>(fmaf(bx.x, dy.x, ax.x + cy.x), bq.y, bq.z, bq.w, c.x, c.y, T0, R0, G0, B0, D0);
-                    if (m & 2) blend_px<kInvDepth>(fmaf(bx.y, dy.x, ax.y + cy.x), bq.y, bq.z, bq.w, c.x, c.y, T1, R1, G1, B1, D1);
-                    if (m & 4) blend_px<kInvDepth>(fmaf(bx.x, dy.y, ax.x + cy.y), bq.y, bq.z, bq.w, c.x, c.y, T2, R2, G2, B2, D2);
-                    if (m & 8) blend_px<kInvDepth>(fmaf(bx.y, dy.y, ax.y + cy.y), bq.y, bq.z, bq.w, c.x, c.y, T3, R3, G3, B3, D3);
-                }
-            };
-            float4 a0 = L.stage[0][0], b0 = L.stage[1][0], c0 = L.stage[2][0], a1, b1, c1;
-            for (int j = 0; j < cnt; j += 2) {
-                a1 = L.stage[0][j + 1], b1 = L.stage[1][j + 1], c1 = L.stage[2][j + 1];  // j + 1 <= 63 (cnt <= 64)
-                blend(a0, b0, c0);
-                if (j + 1 >= cnt) break;
-                const int jn = min(j + 2, 63);
-                a0 = L.stage[0][jn], b0 = L.stage[1][jn], c0 = L.stage[2][jn];
-                blend(a1, b1, c1);
-                if ((j & 7) == 6) {  // a quadrant whose 64 pixels are all finished takes no further Gaussians
-                    qalive = (__any(T0 > 0.f) ? 1 : 0) | (__any(T1 > 0.f) ? 2 : 0) | (__any(T2 > 0.f) ? 4 : 0) |
-                             (__any(T3 > 0.f) ? 8 : 0);
-                    if (!qalive) break;
-                }
-            }
+            if (base + 64 + lane < n) load_records(base + 64 + lane);
+#if AMAV_ABLATE == 3 || AMAV_ABLATE == 7 || AMAV_ABLATE == 8  /* diagnostic build: no blending at all */
+            if (false)
+#endif
+            if (m0 && !blend_quadrant<kInvDepth>(m0, L, pxf0, pyf0, T0, R0, G0, B0, D0)) qalive &= ~1;
+#if AMAV_ABLATE != 3 && AMAV_ABLATE != 7 && AMAV_ABLATE != 8
+            if (m1 && !blend_quadrant<kInvDepth>(m1, L, pxf1, pyf0, T1, R1, G1, B1, D1)) qalive &= ~2;
+            if (m2 && !blend_quadrant<kInvDepth>(m2, L, pxf0, pyf1, T2, R2, G2, B2, D2)) qalive &= ~4;
+            if (m3 && !blend_quadrant<kInvDepth>(m3, L, pxf1, pyf1, T3, R3, G3, B3, D3)) qalive &= ~8;
+#endif
             wave_sync();
         }
     }
@@ -954,6 +1028,9 @@ __device__ __forceinline__ void render_tile(const Params &p, WaveLds &L, int ite
                 bl = fminf(fmaxf(bl, 0.f), 1.f);
             }
             const size_t pid = ((size_t)f * p.H + py) * p.W + px;
+#if AMAV_ABLATE == 6 || AMAV_ABLATE == 8
+            if (r == 123.f)  /* diagnostic build: no tile stores */
+#endif
             reinterpret_cast<float4 *>(p.out_rgba)[pid] = make_float4(r, g, bl, 1.0f - Tq[q]);
             if (kInvDepth) p.out_inv_depth[pid] = Dq[q];
         }
@@ -961,43 +1038,53 @@ __device__ __forceinline__ void render_tile(const Params &p, WaveLds &L, int ite
     AMAV_STAMP(4);
 }
 
-__device__ __forceinline__ int xcc_id() {
-    int v;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
-    return v & (kQueues - 1);
-}
-
-// Blend kernel.  One workgroup = one wave = one non-empty tile + a share of the background tiles (four tiles per
-// workgroup held every slot until the slowest of the four was done: 4000-4400 of 5120 wave slots busy in mid-kernel
-// against 4700-5000 now).  Tiles are taken from bucketed lists, LONGEST LISTS FIRST: on this chip a dispatch recycles workgroup slots in dispatch order,
-// so a grid that mixes empty and long tiles strands most slots behind the long ones (measured 1.5 of 5 slots per CU
-// busy with one block per tile quad); with neighbours of similar length the hardware dispatcher balances the load.
-// Block b reads queue b % 8: blocks are dealt round-robin over the XCDs, so an XCD's L2 keeps seeing the frames of
-// its own queue (a placement assumption that only affects speed).
+// Blend kernel: PERSISTENT waves (one wave per workgroup, the grid is what the chip holds at once).  The waves of
+// queue q (= blockIdx % 8: blocks are dealt round-robin over the XCDs, so an XCD keeps seeing the tile-row bands of
+// its own queue -- a placement assumption that only affects speed) walk the queue's buckets, which are ordered
+// LONGEST LISTS FIRST, so the kernel ends on the shortest tiles.  The first position of a wave is static; every later
+// one comes from the queue's cursor (one returning atomic per tile on one of eight words, issued a tile ahead so its
+// round trip hides under the blending: ~16 dequeues per microsecond and word, far below the ~88 a word sustains).
+// (Round 1 launched one workgroup per possible tile -- 256 000 of them for 51 000 non-empty tiles; the 205 000 waves
+// that only wrote background held an eighth of the wave slots.)  After each tile the wave writes a share of its
+// background tiles, so those stores stay spread over the whole kernel, under the VALU-bound blending.
 template <bool kInvDepth>
-__global__ __launch_bounds__(64 * kRenderWaves) void render_kernel(Params p) {
-    __shared__ WaveLds lds4[kRenderWaves];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+__global__ __launch_bounds__(64, kRenderWavesPerSimd) void render_kernel(Params p) {
+    __shared__ WaveLds lds;
+    const int lane = threadIdx.x;
     const Status *st = p.buf.status;
-    const int gw = blockIdx.x * kRenderWaves + wave;
+    const int nempty = st->nempty;
+    const int nw = gridDim.x, per = (nempty + nw - 1) / nw;
+    int e0 = min(nempty, (int)blockIdx.x * per);
+    const int e1 = min(nempty, e0 + per);
     if (!st->overflow) {
-        const int q = blockIdx.x % kQueues;
-        const int i = (blockIdx.x / kQueues) * kRenderWaves + wave;  // position in queue q's concatenated buckets
-        int acc = 0, b = 0;
-        for (; b < kBuckets; ++b) {
-            const int c = st->qcount[q][b];
-            if (i < acc + c) break;
-            acc += c;
-        }
-        if (b < kBuckets) {  // wave-uniform: keep the tile id (and everything derived from it) in scalar registers
+        const int q = blockIdx.x % kQueues, stride = gridDim.x / kQueues;
+        int total = 0;
+        for (int b = 0; b < kBuckets; ++b) total += st->qcount[q][b];
+        // expected tiles per wave, to spread this wave's background tiles over its blended ones
+        const int expect = max(1, (total + stride - 1) / stride);
+        const int fill_chunk = (e1 - e0 + expect - 1) / expect;
+        int *next = const_cast<int *>(&st->next[q][0]);
+        int i = blockIdx.x / kQueues;  // first round: static; afterwards the queue's shared cursor
+        while (i < total) {
+            // take the following position now: the atomic's round trip hides under this tile
+            int nxt = 0;
+            if (lane == 0) nxt = stride + atomicAdd(next, 1);
+            int b = 0, acc = 0;
+            while (i >= acc + st->qcount[q][b]) acc += st->qcount[q][b++];  // i < total: b stays inside the table
+            // wave-uniform: keep the tile id (and everything derived from it) in scalar registers
             const int item = __builtin_amdgcn_readfirstlane(p.buf.queue[((size_t)q * kBuckets + b) * p.qcap + (i - acc)]);
-            render_tile<kInvDepth>(p, lds4[wave], item, lane);
+            render_tile<kInvDepth>(p, lds, item, lane);
+#if AMAV_ABLATE != 5 && AMAV_ABLATE != 7 && AMAV_ABLATE != 8
+            for (const int stop = min(e1, e0 + fill_chunk); e0 < stop; ++e0) fill_tile<kInvDepth>(p, p.buf.empty_list[e0], lane);
+#endif
+            i = __builtin_amdgcn_readfirstlane(nxt);
         }
     }
-    // background tiles (every tile when the instance regions overflowed: the caller must retry)
-    const int nempty = st->nempty;
-    const int nw = gridDim.x * kRenderWaves, per = (nempty + nw - 1) / nw;
-    for (int k = gw * per; k < min(nempty, (gw + 1) * per); ++k) fill_tile<kInvDepth>(p, p.buf.empty_list[k], lane);
+    // the rest of this wave's background tiles (all of them when it had no tile to blend; every tile of the launch
+    // when the instance regions overflowed: the caller must retry)
+#if AMAV_ABLATE != 5 && AMAV_ABLATE != 7 && AMAV_ABLATE != 8
+    for (; e0 < e1; ++e0) fill_tile<kInvDepth>(p, p.buf.empty_list[e0], lane);
+#endif
 }
 
 }  // namespace raster
@@ -1005,6 +1092,28 @@ __global__ __launch_bounds__(64 * kRenderWaves) void render_kernel(Params p) {
 
 using namespace amav;
 using namespace amav::raster;
+
+// Resident waves of the blend kernel (the persistent grid).  A grid above the true residency only delays the surplus
+// waves' first tile; AMAV_RENDER_WAVES (waves per CU) overrides the default for tuning.
+static unsigned render_grid(bool /*inv_depth*/) {
+    static unsigned g = 0;
+    if (g) return g;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        cus = 256;
+    (void)hipGetLastError();
+    // __launch_bounds__(64, kRenderWavesPerSimd) caps the registers so that many one-wave workgroups fit on a SIMD;
+    // their LDS (7 KiB each) fits 22 times into a CU's 160 KiB.  (hipOccupancyMaxActiveBlocksPerMultiprocessor
+    // answers 16 for this kernel on ROCm 7.2 although 20 are resident.)
+    int per_cu = 4 * kRenderWavesPerSimd;
+    if (const char *env = getenv("AMAV_RENDER_WAVES")) {
+        const int v = atoi(env);
+        if (v >= 1 && v <= 32) per_cu = v;
+    }
+    g = (unsigned)(cus * per_cu) / kQueues * kQueues;
+    if (g < (unsigned)kQueues) g = kQueues;
+    return g;
+}
 
 extern "C" size_t amav_rasterize_workspace_bytes(int F, int N, int H, int W, int64_t capacity) {
     if (F <= 0 || N <= 0 || H <= 0 || W <= 0 || capacity < 0) return 0;
@@ -1081,14 +1190,13 @@ extern "C" int amav_rasterize_forward(const amav_raster_args *a, void *stream_) 
     else
         bin_kernel<false><<<F, 1024, bin_lds, stream>>>(p);
     sort_big_kernel<<<kBigBlocks, 256, 0, stream>>>(p);
-    // worst-case grid (every tile non-empty in one queue); must be a multiple of kQueues
-    const long long per_queue = ((long long)p.qcap + kRenderWaves - 1) / kRenderWaves;
-    const unsigned blocks = (unsigned)(per_queue * kQueues);
+    // persistent grid: the waves the chip holds at once (a multiple of kQueues)
+    const unsigned blocks = render_grid(a->out_inv_depth != nullptr);
     if (a->profile_start_event) (void)hipEventRecord(static_cast<hipEvent_t>(a->profile_start_event), stream);
     if (a->out_inv_depth)
-        render_kernel<true><<<blocks, 64 * kRenderWaves, 0, stream>>>(p);
+        render_kernel<true><<<blocks, 64, 0, stream>>>(p);
     else
-        render_kernel<false><<<blocks, 64 * kRenderWaves, 0, stream>>>(p);
+        render_kernel<false><<<blocks, 64, 0, stream>>>(p);
     if (a->profile_stop_event) (void)hipEventRecord(static_cast<hipEvent_t>(a->profile_stop_event), stream);
     return check_launch("amav_rasterize_forward");
 }

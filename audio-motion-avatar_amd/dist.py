@@ -82,7 +82,8 @@ class FrameAllGather:
 
     wire="sparse" (default): only the 16x16 tiles that differ from the background travel (ops.frames_pack_tiles), and
     every rank unpacks the gathered buffers back into dense uint8 frames -- lossless, ~1/5 of the bytes for an avatar
-    clip.  The per-rank tile capacity is fixed by calibrate() (a synchronising call, made once before the timed
+    clip.  The two dense output buffers are reused, so the unpack is differential: it writes the stored tiles and
+    re-clears only the tiles that held pixels in the buffer's previous use (ops.frames_unpack_tiles(state=...)).  The per-rank tile capacity is fixed by calibrate() (a synchronising call, made once before the timed
     region: max stored tiles over the ranks + 10 %); a later step that needs more sets `overflowed()`, exactly like
     the rasterizer's instance capacity.  wire="dense": plain uint8 RGB frames (ops.frames_to_rgb8).
     """
@@ -105,6 +106,12 @@ class FrameAllGather:
         else:
             self.capacity = None
             self.status = torch.zeros(1, dtype=torch.int32, device=device)
+            # differential unpack (width % 16 == 0): each dense buffer is reused every other step and ~80 % of an
+            # avatar frame is background, so only stored tiles and tiles the body moved out of are rewritten
+            from . import ops
+
+            self.tile_state = ([ops.frames_tile_state(world_size, frames, height, width, device) for _ in range(2)]
+                               if width % 16 == 0 else [None, None])
 
     # ---- sparse wire -------------------------------------------------------------------------------------------------
     def calibrate(self, rgba: torch.Tensor, headroom=1.1, tile_hint=None):
@@ -160,7 +167,7 @@ class FrameAllGather:
                                       tile_hint=tile_hint)
                 dist.all_gather_into_tensor(self.gathered[i].view(-1), self.local[i], group=self.group)
                 ops.frames_unpack_tiles(self.gathered[i], self.world, F, H, W, self.capacity, out=self.full[i],
-                                        status=self.status)
+                                        status=self.status, state=self.tile_state[i])
         return self.full[i]
 
     def wait(self):

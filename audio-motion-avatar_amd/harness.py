@@ -173,27 +173,27 @@ class AudioDrivenAvatar(nn.Module):
             net = self.audio_triplane
             tri_shape = (per, net.cfg.triplane_feature_dim, net.triplane_token_len)
             smpl_shape = (per, net.cfg.smpl_token_dim, net.smplx_token_len)
+            local = None
             if rank == 0:
-                mine, pending, block = None, [], []
+                pending, block = [], []
                 for w, (tri, smpl) in enumerate(self.rollout_tokens(triplanes, smplx_tokens, audio_features, windows)):
                     block.append((tri[0], smpl[0]))
                     if (w + 1) % (w1 - w0) == 0:  # a rank's block is complete: hand it over, keep generating
                         dst = w // (w1 - w0)
                         tri_b = torch.cat([b[0] for b in block]).contiguous()
                         smpl_b = torch.cat([b[1] for b in block]).contiguous()
-                        if dst == 0:
-                            mine = (tri_b, smpl_b)
+                        if dst == 0:  # its own block comes first: enqueue its frames now, ahead of the later blocks' steps
+                            local = self.renderer(tri_b.unsqueeze(0), cam, smpl_b.unsqueeze(0))[0]
                         else:
                             pending += [(send_frames(tri_b, dst, group), tri_b), (send_frames(smpl_b, dst, group), smpl_b)]
                         block = []
                 for req, _keep in pending:
                     req.wait()
-                tri_l, smpl_l = mine
             else:
                 dev, dt = triplanes.device, triplanes.dtype
                 tri_l = recv_frames(tri_shape, dt, dev, 0, group)
                 smpl_l = recv_frames(smpl_shape, dt, dev, 0, group)
-            local = self.renderer(tri_l.unsqueeze(0), cam, smpl_l.unsqueeze(0))[0]
+                local = self.renderer(tri_l.unsqueeze(0), cam, smpl_l.unsqueeze(0))[0]
         else:
             raise ValueError(f"unknown mode {mode!r}")
         rgba = torch.cat([local[0], torch.ones_like(local[0][..., :1])], dim=-1).contiguous()

@@ -263,24 +263,45 @@ def frames_wire_count(wire):
     return int(head[1]), int(head[2])
 
 
-def frames_unpack_tiles(wire_all, num_buffers, F, H, W, capacity_tiles, out=None, status=None):
+def frames_unpack_tiles(wire_all, num_buffers, F, H, W, capacity_tiles, out=None, status=None, state=None):
     """`num_buffers` gathered wire buffers (a uint8 tensor [num_buffers, stride]) -> uint8 RGB [num_buffers*F,H,W,3].
-    `status` (int32 [1], accumulated) becomes non-zero when a sender had to drop tiles."""
+    `status` (int32 [1], accumulated) becomes non-zero when a sender had to drop tiles.
+
+    `state` (int32 [num_buffers * F * tiles], made by frames_tile_state()) selects the differential form for an `out`
+    buffer that is reused from step to step: only stored tiles and tiles that must return to background are written
+    (include/amav.h, amav_frames_unpack_tiles_delta); `state` belongs to `out` and is updated in place."""
     wire_all = _need(wire_all, "wire_all", torch.uint8)
     if wire_all.dtype != torch.uint8 or not wire_all.is_contiguous() or wire_all.dim() != 2 or \
             wire_all.shape[0] != num_buffers:
         raise AmavError("frames_unpack_tiles: wire_all must be a contiguous uint8 [num_buffers, stride] tensor")
     dev = wire_all.device
     if out is None:
+        if state is not None:
+            raise AmavError("frames_unpack_tiles: `state` describes a buffer the caller keeps: pass it as `out`")
         out = torch.empty(num_buffers * F, H, W, 3, dtype=torch.uint8, device=dev)
     elif tuple(out.shape) != (num_buffers * F, H, W, 3) or out.dtype != torch.uint8 or not out.is_contiguous():
         raise AmavError(f"frames_unpack_tiles: out must be contiguous uint8 {(num_buffers * F, H, W, 3)}")
     if status is None:
         status = torch.zeros(1, dtype=torch.int32, device=dev)
+    if state is not None:
+        tiles = num_buffers * F * ((H + 15) // 16) * ((W + 15) // 16)
+        state = _need(state, "state", torch.int32)
+        if state.numel() != tiles or not state.is_contiguous():
+            raise AmavError(f"frames_unpack_tiles: state must be a contiguous int32 tensor of {tiles} entries")
+        check(_lib.lib().amav_frames_unpack_tiles_delta(int(num_buffers), int(F), int(H), int(W), int(capacity_tiles),
+                                                        wire_all.data_ptr(), wire_all.shape[1], out.data_ptr(),
+                                                        state.data_ptr(), status.data_ptr(), _stream()),
+              "amav_frames_unpack_tiles_delta")
+        return out, status
     check(_lib.lib().amav_frames_unpack_tiles(int(num_buffers), int(F), int(H), int(W), int(capacity_tiles),
                                               wire_all.data_ptr(), wire_all.shape[1], out.data_ptr(), status.data_ptr(),
                                               _stream()), "amav_frames_unpack_tiles")
     return out, status
+
+
+def frames_tile_state(num_buffers, F, H, W, device):
+    """Fresh per-tile state of a reusable dense output buffer for the differential unpack: every tile unknown (-1)."""
+    return torch.full((num_buffers * F * ((H + 15) // 16) * ((W + 15) // 16),), -1, dtype=torch.int32, device=device)
 
 
 # ------------------------------------------------------------------------------------------------------------ LBS

@@ -136,7 +136,12 @@ int amav_frames_to_rgb8(int64_t num_pixels, const float *rgba_dev, uint8_t *out_
  *   amav_rasterize_tile_counts (a tile without Gaussians); with a hint the frames are read for the stored tiles only.
  * amav_frames_unpack_tiles: `num_buffers` gathered wire buffers (rank r at wire_all + r * wire_stride) -> dense uint8
  *   RGB [num_buffers * F, H, W, 3]; status[0] |= 1 if any buffer was truncated or is not a wire buffer (the caller
- *   re-packs with more room, as with the rasterizer's instance capacity).  No host synchronisation in either call. */
+ *   re-packs with more room, as with the rasterizer's instance capacity).  No host synchronisation in either call.
+ * amav_frames_unpack_tiles_delta: the same into an output buffer that is REUSED from step to step (width % 16 == 0).
+ *   tile_state int32 [num_buffers * F * tiles per frame] belongs to that output buffer and records what every tile
+ *   of it holds: the background word 0x00BBGGRR it was last cleared to, or -1 (rendered pixels / unknown -- a fresh
+ *   buffer's state is all -1).  Only the tiles stored on the wire, and the tiles that are background now but do not
+ *   hold this background yet, are written; the state is updated in the same launch. */
 /* Per-tile Gaussian list lengths of the last amav_rasterize_forward on this workspace, int32 [F * tiles per frame]
  * (frame-major, tiles row-major; all ones after an instance-capacity overflow).  Same sizes as the forward call. */
 int amav_rasterize_tile_counts(const void *workspace, int num_frames, int num_gaussians, int height, int width,
@@ -148,6 +153,9 @@ int amav_frames_pack_tiles(int num_frames, int height, int width, const float *r
 int amav_frames_unpack_tiles(int num_buffers, int num_frames, int height, int width, int64_t capacity_tiles,
                              const void *wire_all_dev, size_t wire_stride, uint8_t *out_rgb8_dev, int32_t *status_dev,
                              void *stream);
+int amav_frames_unpack_tiles_delta(int num_buffers, int num_frames, int height, int width, int64_t capacity_tiles,
+                                   const void *wire_all_dev, size_t wire_stride, uint8_t *out_rgb8_dev,
+                                   int32_t *tile_state_dev, int32_t *status_dev, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * SMPL-X forward + linear blend skinning for F frames.

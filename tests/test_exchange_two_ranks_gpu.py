@@ -26,21 +26,29 @@ def _worker(rank, world, port, out):
         F, H, W = 6, 128, 160
         cfg = RendererConfig(image_size=(H, W), subdivide_steps=0, predict_smplx_params=False, device="cuda")
         r = init_random_heads(Renderer(cfg).eval())
-        shards = []
+        gens = []  # two generations of every rank's shard: the body moves, so tiles appear and disappear between them
         with torch.no_grad():
-            for rk in range(world):  # every rank renders every shard, so it knows what the gather must deliver
-                tokens, smpl, cam = make_render_inputs(F, cfg, seed=100 + rk, device="cuda")
-                ws = [None]
-                rgba, _ = r.render_tokens(tokens[0], smpl, cam, workspaces=ws)
-                shards.append((rgba.clone(), ws[0].tile_counts().clone()))
-        want = torch.cat([ops.frames_to_rgb8(s[0]) for s in shards])
+            for gen in range(2):
+                shards = []
+                for rk in range(world):  # every rank renders every shard, so it knows what the gather must deliver
+                    tokens, smpl, cam = make_render_inputs(F, cfg, seed=100 + rk + 50 * gen, device="cuda")
+                    smpl["transl"][..., 0] += 0.35 * gen
+                    ws = [None]
+                    rgba, _ = r.render_tokens(tokens[0], smpl, cam, workspaces=ws)
+                    shards.append((rgba.clone(), ws[0].tile_counts().clone()))
+                gens.append((shards, torch.cat([ops.frames_to_rgb8(s[0]) for s in shards])))
+        assert not torch.equal(gens[0][1], gens[1][1])
         ok = {}
         for wire in ("sparse", "dense"):
             gather = FrameAllGather(F, H, W, world, "cuda", wire=wire)
-            mine, hint = shards[rank]
             if wire == "sparse":
-                gather.calibrate(mine, tile_hint=hint)
-            for _ in range(3):  # both buffers of the double buffering, and a reuse
+                gather.calibrate(gens[0][0][rank][0], headroom=2.0, tile_hint=gens[0][0][rank][1])
+                assert gather.tile_state[0] is not None  # W % 16 == 0: the differential unpack is what runs
+            # both buffers of the double buffering, reuses with the same frames, and reuses after the frames changed
+            # (the differential unpack must re-clear the tiles the body left)
+            for gen in (0, 0, 0, 1, 1, 0, 1, 0, 0):
+                shards, want = gens[gen]
+                mine, hint = shards[rank]
                 full = gather.submit(mine, tile_hint=hint if wire == "sparse" else None)
                 gather.wait()
                 torch.cuda.synchronize()

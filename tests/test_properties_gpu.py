@@ -208,6 +208,41 @@ def test_sparse_wire_with_the_rasterizer_tile_hint(full_clip):
     assert torch.equal(dense, ops.frames_to_rgb8(rgba)) and int(status.item()) == 0
 
 
+def test_differential_unpack_equals_the_full_unpack_over_a_sequence_of_steps(full_clip):
+    """amav_frames_unpack_tiles_delta into a REUSED dense buffer == amav_frames_unpack_tiles into a fresh one, for a
+    sequence in which tiles appear, disappear and the background colour changes; an unchanged step rewrites nothing
+    but the stored tiles (checked by poisoning a background tile: it must survive)."""
+    from audio_motion_avatar_amd import ops
+
+    nb, Fs = 3, 8
+    steps = [(slice(0, 24), (1.0, 1.0, 1.0)), (slice(0, 24), (1.0, 1.0, 1.0)), (slice(100, 124), (1.0, 1.0, 1.0)),
+             (slice(30, 54), (0.0, 0.5, 1.0)), (slice(30, 54), (0.0, 0.5, 1.0)), (slice(0, 24), (1.0, 1.0, 1.0))]
+    out = torch.empty(nb * Fs, H, W, 3, dtype=torch.uint8, device="cuda").random_(0, 255)  # garbage to start with
+    state = ops.frames_tile_state(nb, Fs, H, W, "cuda")
+    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for i, (sel, bg) in enumerate(steps):
+        rgba = raster(full_clip, sel=sel, clamp_output=True, bg=bg)["rgba"].view(nb, Fs, H, W, 4)
+        count = max(ops.frames_wire_count(ops.frames_pack_tiles(rgba[b], 0, bg))[0] for b in range(nb))
+        wires = torch.stack([ops.frames_pack_tiles(rgba[b], count, bg) for b in range(nb)])
+        want, _ = ops.frames_unpack_tiles(wires, nb, Fs, H, W, count)
+        if i == 1:  # same frames again: a background tile must not be touched
+            assert bool((want[0, :16, :16] == 255).all())
+            out[0, :16, :16] = 7
+        ops.frames_unpack_tiles(wires, nb, Fs, H, W, count, out=out, status=status, state=state)
+        if i == 1:
+            assert bool((out[0, :16, :16] == 7).all()), "an unchanged background tile was rewritten"
+            out[0, :16, :16] = 255
+        assert torch.equal(out, want), f"step {i}"
+    assert int(status.item()) == 0
+    # a truncated sender: the dropped tiles read as background and the status flag is raised, as in the full unpack
+    rgba = raster(full_clip, sel=slice(0, 24), clamp_output=True)["rgba"].view(nb, Fs, H, W, 4)
+    count = min(ops.frames_wire_count(ops.frames_pack_tiles(rgba[b], 0))[0] for b in range(nb)) // 2
+    wires = torch.stack([ops.frames_pack_tiles(rgba[b], count) for b in range(nb)])
+    want, st_full = ops.frames_unpack_tiles(wires, nb, Fs, H, W, count)
+    ops.frames_unpack_tiles(wires, nb, Fs, H, W, count, out=out, status=status, state=state)
+    assert torch.equal(out, want) and int(status.item()) == 1 and int(st_full.item()) == 1
+
+
 def test_render_step_is_hip_graph_capturable(full_clip):
     """no entry point of the C ABI allocates or synchronises, so one pass of the hot path (slab
     projection + camera + LBS + fused decode + clear + binning + sort + blend, ONE stream, kernel nodes only) captures

@@ -48,3 +48,21 @@ for nb in (1, 8):
     status = torch.zeros(1, dtype=torch.int32, device="cuda")
     timeit(f"unpack {nb} gathered shard(s)", lambda: ops.frames_unpack_tiles(stack, nb, F, H, W, cap, out=out, status=status))
     assert torch.equal(out[:F], ops.frames_to_rgb8(rgba)) and int(status.item()) == 0
+    # differential unpack into the same (reused) buffer: steady state = the same tiles every step
+    state = ops.frames_tile_state(nb, F, H, W, "cuda")
+    out.random_(0, 255)
+    timeit(f"delta unpack {nb} shard(s), steady", lambda: ops.frames_unpack_tiles(stack, nb, F, H, W, cap, out=out, status=status, state=state))
+    assert torch.equal(out[:F], ops.frames_to_rgb8(rgba)) and int(status.item()) == 0
+    # worst case for the differential form: every step the body sits elsewhere (alternate two different shards)
+    rgba2 = torch.roll(rgba, shifts=(64, 96), dims=(1, 2)).contiguous()
+    wire2 = ops.frames_pack_tiles(rgba2, cap)
+    stack2 = wire2[None].repeat(nb, 1)
+    flip = [0]
+
+    def alternate():
+        flip[0] ^= 1
+        ops.frames_unpack_tiles(stack2 if flip[0] else stack, nb, F, H, W, cap, out=out, status=status, state=state)
+
+    timeit(f"delta unpack {nb} shard(s), moving", alternate)
+    ops.frames_unpack_tiles(stack, nb, F, H, W, cap, out=out, status=status, state=state)
+    assert torch.equal(out[:F], ops.frames_to_rgb8(rgba))

@@ -30,7 +30,7 @@ __global__ __launch_bounds__(64) void probe(float *out, unsigned long long *cyc,
             FMA(a0); FMA(a0); FMA(a0); FMA(a0); FMA(a0); FMA(a0); FMA(a0); FMA(a0);
         } else if (MODE == 4) {  // 8 v_fma_f32 interleaved with 8 SALU instructions
             int s = i;
-#define SALU(x) asm volatile("s_add_i32 %0, %0, 3" : "+s"(x))
+#define SALU(x) asm volatile("s_add_i32 %0, %0, 3" : "+s"(x) : : "scc")
             FMA(a0); SALU(s); FMA(a1); SALU(s); FMA(a2); SALU(s); FMA(a3); SALU(s);
             FMA(a4); SALU(s); FMA(a5); SALU(s); FMA(a6); SALU(s); FMA(a7); SALU(s);
             asm volatile("" :: "s"(s));
@@ -77,6 +77,7 @@ static void run(const char *name, int per_iter, float *d, unsigned long long *dc
         printf("%-28s waves/SIMD %d: kernel %.3f ms; wave ticks/iter %.2f; SIMD-time per wave-instruction %.3f ns "
                "(= %.2f cycles at 2.4 GHz)\n", name, wps, ms, wave_cyc / iters,
                ms * 1e6 / ((double)iters * per_iter * wps), ms * 1e-3 * 2.4e9 / ((double)iters * per_iter * wps));
+        fflush(stdout);
     }
 }
 
