@@ -37,20 +37,60 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def pmc_traffic_bytes(kernel_substr):
-    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC summary of this same command
-    (profiles/r01_bench_render_pmc_hbm.csv: separate FETCH_SIZE / WRITE_SIZE passes, values in KB; see
-    profiles/README.md for the gfx950 caveats).  None when the summary is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_bench_render_pmc_hbm.csv")
+PROFILE_TAG = "r02"  # the committed rocprofv3 summaries of THIS build (tools/gpu_profiles.sh + collect_profiles.py)
+
+
+def _profile_row(filename, kernel_substr):
+    """Row (dict of floats) of a kernel in a committed counter summary under profiles/, or None."""
+    import csv
+
+    path = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_{filename}")
     try:
         with open(path) as fh:
-            for line in fh.read().splitlines()[1:]:
-                cols = line.rsplit(",", 3)
-                if kernel_substr in cols[0]:
-                    return (float(cols[2]) + float(cols[3])) * 1024.0
-    except (OSError, ValueError, IndexError):
+            for row in csv.DictReader(fh):
+                if kernel_substr in row["kernel"]:
+                    return {k: float(v) for k, v in row.items() if k not in ("kernel", "") and v not in ("", "nan")}
+    except (OSError, ValueError, KeyError):
         pass
     return None
+
+
+def pmc_traffic_bytes(kernel_substr):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC summary of this same command
+    (profiles/r02_bench_render_pmc_hbm.csv: separate FETCH_SIZE / WRITE_SIZE passes, values in KB; see
+    profiles/README.md for the gfx950 caveats).  None when the summary is absent."""
+    row = _profile_row("bench_render_pmc_hbm.csv", kernel_substr)
+    if not row:
+        return None
+    return (row["FETCH_SIZE_KB_per_launch"] + row["WRITE_SIZE_KB_per_launch"]) * 1024.0
+
+
+def pmc_issue_fractions(kernel_substr):
+    """Vector-ALU issue occupancy of a kernel from the committed SQ counter passes (profiles/r02_bench_render_pmc_sq.csv):
+    issued VALU wave-instructions x cycles each, over (1024 SIMDs x the launch's cycles = GRBM_GUI_ACTIVE / 8 XCDs).
+    A wave64 VALU instruction occupies a SIMD for 2.13 cycles with >= 5 waves resident (tools/valu_rate_probe.hip,
+    profiles/r02_valu_rate_probe.txt); VERDICT r1 asked for the 4-cycle form (one wave alone), reported beside it."""
+    row = _profile_row("bench_render_pmc_sq.csv", kernel_substr)
+    if not row or not row.get("GRBM_GUI_ACTIVE"):
+        return None
+    simd_cycles = 1024.0 * row["GRBM_GUI_ACTIVE"] / 8.0
+    out = {"valu_wave_instructions_per_launch": row["SQ_INSTS_VALU"], "salu_per_launch": row.get("SQ_INSTS_SALU"),
+           "lds_per_launch": row.get("SQ_INSTS_LDS"), "launch_cycles": row["GRBM_GUI_ACTIVE"] / 8.0,
+           "valu_issue_frac": row["SQ_INSTS_VALU"] * 2.13 / simd_cycles,
+           "valu_issue_frac_4_cycle_form": row["SQ_INSTS_VALU"] * 4.0 / simd_cycles,
+           "all_issue_frac": (row["SQ_INSTS_VALU"] * 2.13 + row.get("SQ_INSTS_SALU", 0.0) * 1.1 +
+                              row.get("SQ_INSTS_LDS", 0.0)) / simd_cycles,
+           "source": f"profiles/{PROFILE_TAG}_bench_render_pmc_sq.csv (profiled launches of the same command)"}
+    return out
+
+
+def pmc_mfma_busy(kernel_substr):
+    """Matrix-pipe occupancy of a kernel: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x launch cycles), from the committed
+    counter pass of tools/bench_attention.py (profiles/r02_attention_transformer_pmc_sq.csv)."""
+    row = _profile_row("attention_transformer_pmc_sq.csv", kernel_substr)
+    if not row or not row.get("GRBM_GUI_ACTIVE") or "SQ_VALU_MFMA_BUSY_CYCLES" not in row:
+        return None
+    return row["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * row["GRBM_GUI_ACTIVE"] / 8.0)
 
 
 def parse():
@@ -204,6 +244,7 @@ class FullPath:
                 "achieved": flop / (ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": flop / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": ms,
                 "algorithmic_flop_per_launch": flop, "launches_timed": len(events),
+                "mfma_busy_frac": pmc_mfma_busy("selfattn_kernel"),
                 "transformer_step": {"ms": step_ms, "flop": step_flop, "achieved": step_flop / (step_ms * 1e-3) / 1e12,
                                      "frac": step_flop / (step_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS}}
 
@@ -621,7 +662,8 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "render_kernel (tile blend)", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": pmc_traffic_bytes("render_kernel") if (F, N, H) == (250, 10000, 512) else None,
-                     "avg_launch_ms": blend_avg_ms, "algorithmic_bytes_per_launch": blend_bytes},
+                     "avg_launch_ms": blend_avg_ms, "algorithmic_bytes_per_launch": blend_bytes,
+                     "issue": pmc_issue_fractions("render_kernel") if (F, N, H) == (250, 10000, 512) else None},
     }
     if args.workload == "stress":  # the stage that dominates this configuration is the slab projection (HBM stream)
         w_plane, _ = renderer._head_weights()
