@@ -85,6 +85,16 @@ SIGNATURES = {
     "amav_frames_unpack_tiles_delta": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                       ctypes.c_int64, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
                                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "amav_cell_max": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_float_p, ctypes.c_void_p,
+                                     ctypes.c_void_p, c_float_p, ctypes.c_void_p]),
+    "amav_cell_gather": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_float_p,
+                                        ctypes.c_void_p, c_float_p, ctypes.c_void_p]),
+    "amav_cell_mean": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_float_p,
+                                      ctypes.c_void_p, ctypes.c_void_p, c_float_p, ctypes.c_void_p]),
+    "amav_points_project_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "amav_points_project": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                           c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_float, c_float_p,
+                                           ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "amav_lbs_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.POINTER(BodyTables)]),
     "amav_lbs_forward": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(BodyTables), c_float_p, c_float_p, c_float_p,
                                         c_float_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),

@@ -9,9 +9,77 @@ trim to the frame count (:107-113).  On-wire format `[T, 768]` fp32 -- what `Aud
 Here the model runs on the MI355X through PyTorch-ROCm library kernels (MIOpen convolutions, rocBLAS GEMMs): this is
 plumbing around the hot path, not one of its hand-written kernels.  The checkpoint `facebook/wav2vec2-base-960h` is
 not available offline; `build_wav2vec2()` constructs the same architecture with random weights (or loads a local
-directory when one is given).  Resampling needs torchaudio (absent): the waveform must already be at `sample_rate`.
+directory when one is given).
+
+Resampling (`torchaudio.transforms.Resample(sr, 16000)`, dataset_speech_vid.py:40-42) and WAV reading
+(`torchaudio.load`, :39) are restated here because torchaudio is absent from this image: `resample()` is torchaudio's
+default band-limited sinc interpolation (Hann window, lowpass_filter_width 6, rolloff 0.99) as one strided
+convolution on the device, `load_wav()` reads PCM WAV files through the standard library.  PARITY UNPINNED for both
+(no torchaudio to compare with); pinned instead by known answers (tests/test_audio_frontend.py: identity at equal
+rates, a sine keeps its frequency and amplitude, band-limiting, length = ceil(n * new / orig)).
 """
+import math
+
 import torch
+import torch.nn.functional as F
+
+
+def load_wav(path):
+    """PCM WAV (8/16/24/32-bit integer) -> (waveform [channels, samples] float32 in [-1, 1), sample_rate), like
+    torchaudio.load(path) with its default normalisation (dataset_speech_vid.py:39)."""
+    import wave
+
+    import numpy as np
+
+    with wave.open(path, "rb") as w:
+        ch, width, sr, n = w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()
+        raw = w.readframes(n)
+    if width == 1:
+        data = (np.frombuffer(raw, dtype=np.uint8).astype(np.float32) - 128.0) / 128.0
+    elif width == 2:
+        data = np.frombuffer(raw, dtype="<i2").astype(np.float32) / 32768.0
+    elif width == 3:
+        b = np.frombuffer(raw, dtype=np.uint8).reshape(-1, 3).astype(np.int32)
+        v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
+        data = np.where(v >= 1 << 23, v - (1 << 24), v).astype(np.float32) / float(1 << 23)
+    elif width == 4:
+        data = np.frombuffer(raw, dtype="<i4").astype(np.float32) / float(1 << 31)
+    else:
+        raise ValueError(f"{path}: unsupported sample width {width}")
+    return torch.from_numpy(data.reshape(-1, ch).T.copy()), sr
+
+
+def _sinc_resample_kernel(orig_freq, new_freq, lowpass_filter_width, rolloff, device):
+    """The polyphase filter bank of torchaudio.functional.resample (sinc_interp_hann): [new, 1, 2*width + orig]."""
+    base_freq = min(orig_freq, new_freq) * rolloff
+    width = math.ceil(lowpass_filter_width * orig_freq / base_freq)
+    idx = torch.arange(-width, width + orig_freq, dtype=torch.float64, device=device)[None, None] / orig_freq
+    t = torch.arange(0, -new_freq, -1, dtype=torch.float64, device=device)[:, None, None] / new_freq + idx
+    t = (t * base_freq).clamp_(-lowpass_filter_width, lowpass_filter_width)
+    window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t = t * math.pi
+    kernels = torch.where(t == 0, torch.ones_like(t), t.sin() / t) * window * (base_freq / orig_freq)
+    return kernels.to(torch.float32), width
+
+
+def resample(waveform, orig_freq, new_freq, lowpass_filter_width=6, rolloff=0.99):
+    """waveform [..., samples] at orig_freq Hz -> [..., ceil(samples * new / orig)] at new_freq Hz."""
+    orig_freq, new_freq = int(orig_freq), int(new_freq)
+    if orig_freq <= 0 or new_freq <= 0:
+        raise ValueError("sample rates must be positive")
+    if orig_freq == new_freq:
+        return waveform
+    g = math.gcd(orig_freq, new_freq)
+    o, n = orig_freq // g, new_freq // g
+    kernel, width = _sinc_resample_kernel(o, n, lowpass_filter_width, rolloff, waveform.device)
+    shape = waveform.shape
+    x = waveform.reshape(-1, shape[-1]).to(torch.float32)
+    length = x.shape[1]
+    x = F.pad(x, (width, width + o))
+    y = F.conv1d(x[:, None], kernel, stride=o)              # [rows, n, frames]
+    y = y.transpose(1, 2).reshape(x.shape[0], -1)
+    target = int(math.ceil(n * length / o))
+    return y[:, :target].reshape(shape[:-1] + (target,))
 
 
 def build_wav2vec2(model_path=None, device="cuda", seed=0):
@@ -34,13 +102,12 @@ def _normalize(clip):
 def extract_audio_features(waveform, sr, frames_count, model, clip_length=8, sample_rate=16000,
                            estimated_frame_rate=30):
     """waveform [channels, samples] (or [samples]) at `sr` Hz -> features [frames_count, hidden] on the model's device."""
-    if sr != sample_rate:
-        raise NotImplementedError(f"resampling {sr} -> {sample_rate} Hz needs torchaudio (absent here); "
-                                  "resample before calling")
     device = next(model.parameters()).device
     waveform = waveform.to(device=device, dtype=torch.float32)
     if waveform.dim() == 1:
         waveform = waveform[None]
+    if sr != sample_rate:                                                    # :40-42
+        waveform = resample(waveform, sr, sample_rate)
     if waveform.shape[0] > 1:
         waveform = waveform.mean(dim=0, keepdim=True)                       # :44-45
     audio_duration = waveform.shape[1] / sample_rate

@@ -49,6 +49,21 @@ class RendererConfig:
 
 
 @dataclass
+class Stage1Config(RendererConfig):
+    """The flattened model config `TriplaneGaussianAvatar` hands to its parts (config_loader.py:190-234): the
+    renderer's fields plus src/configs/model/triplane_net.yaml:10-30 and sapiens_encoder.yaml:3."""
+    smplx_transformer_layers: int = 4
+    smplx_transformer_head_dim: int = 64
+    smplx_transformer_num_heads: int = 8
+    cross_transformer_layers: int = 8
+    cross_transformer_head_dim: int = 64
+    cross_transformer_num_heads: int = 8
+    image_feature_dim: int = 1536
+    sample_feature: bool = True
+    upsample_factor: int = 3
+
+
+@dataclass
 class AudioNetConfig:
     # src/configs/model/triplane_audio_net.yaml:3-14
     triplane_input_frames: int = 2

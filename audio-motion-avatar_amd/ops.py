@@ -458,6 +458,74 @@ def triplane_sample_features(planes, points, radius):
     return out
 
 
+# ---------------------------------------------------------------------------------------------- stage-1 reductions
+def cell_segments(cell_of, cells):
+    """cell_of int [..., N] (cell of every point) -> (order int32 [..., N], seg int32 [..., cells + 1]): point ids
+    stably sorted by cell and the offset of every cell's run.  Plumbing (library sort / bincount), feeds the segment
+    kernels below."""
+    flat = cell_of.reshape(-1, cell_of.shape[-1]).long()
+    order = torch.argsort(flat, dim=1, stable=True)
+    counts = torch.zeros(flat.shape[0], cells, dtype=torch.long, device=flat.device)
+    counts.scatter_add_(1, flat, torch.ones_like(flat))
+    seg = torch.zeros(flat.shape[0], cells + 1, dtype=torch.long, device=flat.device)
+    seg[:, 1:] = counts.cumsum(1)
+    shape = tuple(cell_of.shape[:-1])
+    return order.to(torch.int32).reshape(shape + (flat.shape[1],)), seg.to(torch.int32).reshape(shape + (cells + 1,))
+
+
+def cell_pool_max(feat, cell_of, cells, segments=None):
+    """pool_local (triplane_net.py:226-238): feat [B,N,C], cell_of int32 [B,3,N] -> [B,N,C]: for each of the three
+    planes the channel-wise maximum over the points that share the point's cell, summed over the planes."""
+    feat = _contig(feat, "feat")
+    B, N, C = feat.shape
+    cell_of = _contig(cell_of, "cell_of", torch.int32)
+    if tuple(cell_of.shape) != (B, 3, N):
+        raise AmavError(f"cell_of must be int32 [B,3,N] = {(B, 3, N)}, got {tuple(cell_of.shape)}")
+    order, seg = segments if segments is not None else cell_segments(cell_of, cells)
+    order, seg = _contig(order, "order", torch.int32), _contig(seg, "seg", torch.int32)
+    cellmax = torch.empty(B, 3, cells, C, device=feat.device)
+    out = torch.empty_like(feat)
+    check(_lib.lib().amav_cell_max(B, N, C, int(cells), feat.data_ptr(), order.data_ptr(), seg.data_ptr(),
+                                   cellmax.data_ptr(), _stream()), "amav_cell_max")
+    check(_lib.lib().amav_cell_gather(B, N, C, int(cells), cellmax.data_ptr(), cell_of.data_ptr(), out.data_ptr(),
+                                      _stream()), "amav_cell_gather")
+    return out
+
+
+def cell_splat_mean(feat, cell_of, cells, segments=None):
+    """generate_plane_features (triplane_net.py:240-244): feat [B,N,C], cell_of int32 [B,N] -> [B,C,cells]: per-cell
+    mean of the points' features (summed in ascending point id), zero for an empty cell."""
+    feat = _contig(feat, "feat")
+    B, N, C = feat.shape
+    cell_of = _contig(cell_of, "cell_of", torch.int32)
+    if tuple(cell_of.shape) != (B, N):
+        raise AmavError(f"cell_of must be int32 [B,N] = {(B, N)}, got {tuple(cell_of.shape)}")
+    order, seg = segments if segments is not None else cell_segments(cell_of, cells)
+    order, seg = _contig(order, "order", torch.int32), _contig(seg, "seg", torch.int32)
+    out = torch.empty(B, C, cells, device=feat.device)
+    check(_lib.lib().amav_cell_mean(B, N, C, int(cells), feat.data_ptr(), order.data_ptr(), seg.data_ptr(),
+                                    out.data_ptr(), _stream()), "amav_cell_mean")
+    return out
+
+
+def points_project(points, w2c, intrinsics, features, radius_px):
+    """points_projection (graphic_utils.py:275-331): points [B,N,3], w2c [B,4,4], intrinsics [B,3,3], features
+    [B,C,H,W] -> [B,N,C] (include/amav.h, amav_points_project)."""
+    points, w2c = _contig(points, "points"), _contig(w2c, "w2c")
+    intrinsics, features = _contig(intrinsics, "intrinsics"), _contig(features, "features")
+    B, N, _ = points.shape
+    _, C, H, W = features.shape
+    if features.shape[0] != B or tuple(w2c.shape) != (B, 4, 4) or tuple(intrinsics.shape) != (B, 3, 3):
+        raise AmavError("points_project: batch sizes / matrix shapes do not match")
+    nbytes = _lib.lib().amav_points_project_workspace_bytes(B, N, H, W)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=points.device)
+    out = torch.empty(B, N, C, device=points.device)
+    check(_lib.lib().amav_points_project(B, N, C, H, W, points.data_ptr(), w2c.data_ptr(), intrinsics.data_ptr(),
+                                         features.data_ptr(), float(radius_px), out.data_ptr(), ws.data_ptr(), nbytes,
+                                         _stream()), "amav_points_project")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------------ attention
 # A list of (Event, Event) pairs: every selfattn() call pops one and records it around its kernels (bench.py)
 ATTN_PROFILE_EVENTS = None

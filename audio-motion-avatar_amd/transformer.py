@@ -57,8 +57,15 @@ class Attention(nn.Module):
             out = ops.selfattn(qkv[..., :i], qkv[..., i:2 * i], qkv[..., 2 * i:], self.heads)
             return self.to_out[0](out)
         if encoder_hidden_states.shape[1] != 1:
-            raise NotImplementedError("cross-attention over more than one context token is not on the reference's "
-                                      "path (triplane_audio_net.py:211 passes audio_features[:, t:t+1])")
+            # Many context tokens (stage 1: 4096 Sapiens tokens, triplane_net.py:104-113,320-329): a SURVEY 8(f)
+            # next-row, on the library's fused attention (the MFMA kernel of csrc/attention.hip is the self-attention
+            # of the audio net: equal query / key lengths).
+            B, S, _ = hidden_states.shape
+            split = lambda t: t.view(B, t.shape[1], self.heads, self.dim_head).transpose(1, 2)
+            q = split(self.to_q(hidden_states))
+            k, v = split(self.to_k(encoder_hidden_states)), split(self.to_v(encoder_hidden_states))
+            o = F.scaled_dot_product_attention(q, k, v)
+            return self.to_out[0](o.transpose(1, 2).reshape(B, S, self.inner_dim))
         # one key: softmax == 1, so the output is to_out(to_v(context)) for every query
         ctx = self.to_out[0](self.to_v(encoder_hidden_states))        # [B,1,query_dim]
         return ctx.expand(-1, hidden_states.shape[1], -1)

@@ -231,6 +231,33 @@ int amav_triplane_sample_features(int num_frames, int num_points, int channels, 
                                   float *out_features_dev, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Stage-1 identity encoder: the point <-> triplane-cell reductions of
+ * SMPLXTriplaneEncoder and the point -> pixel feature lookup, deterministic segment reductions.
+ * Replaces torch_scatter.scatter_max / scatter_mean as used at src/models/triplane_net.py:226-244 and the pytorch3d
+ * point rasterizer + index_put of points_projection (src/utils/graphic_utils.py:275-331).
+ *   order [B,3,N] (amav_cell_max) / [B,N] (amav_cell_mean): point ids sorted by cell (stable); seg [.., cells + 1]:
+ *   offsets of every cell's run in `order`; cell_of [B,3,N]: cell of every point per plane.
+ * amav_cell_max:    cellmax [B,3,cells,C] = per-cell channel-wise maximum of feat [B,N,C] (0 for an empty cell)
+ * amav_cell_gather: out [B,N,C] = cellmax[plane 0] + cellmax[plane 1] + cellmax[plane 2] at the point's cells
+ *                   (pool_local, triplane_net.py:226-238)
+ * amav_cell_mean:   out_planes [B,C,cells] = per-cell mean of feat [B,N,C], summed in ascending point id, 0 if empty
+ *                   (generate_plane_features, triplane_net.py:240-244)
+ * amav_points_project: points [B,N,3] (world), w2c [B,4,4] row-major, intrinsics [B,3,3] (OpenCV pixels), features
+ *   [B,C,H,W] -> out [B,N,C]: z-buffer of discs of radius_px around the projected points (pixel centres at +0.5);
+ *   a point that is the nearest one at some pixel takes the features of the LAST such pixel in (y, x) order, every
+ *   other point zeros. */
+int amav_cell_max(int batch, int num_points, int channels, int cells, const float *feat_dev, const int32_t *order_dev,
+                  const int32_t *seg_dev, float *cellmax_dev, void *stream);
+int amav_cell_gather(int batch, int num_points, int channels, int cells, const float *cellmax_dev,
+                     const int32_t *cell_of_dev, float *out_dev, void *stream);
+int amav_cell_mean(int batch, int num_points, int channels, int cells, const float *feat_dev, const int32_t *order_dev,
+                   const int32_t *seg_dev, float *out_planes_dev, void *stream);
+size_t amav_points_project_workspace_bytes(int batch, int num_points, int height, int width);
+int amav_points_project(int batch, int num_points, int channels, int height, int width, const float *points_dev,
+                        const float *w2c_dev, const float *intrinsics_dev, const float *features_dev, float radius_px,
+                        float *out_dev, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Self-attention of the audio transformer (diffusers Attention -> F.scaled_dot_product_attention as reached from
  * src/models/transformers.py:329-336): softmax(Q K^T * scale) V, fp32 in/out, no mask, on MFMA
  * (v_mfma_f32_32x32x2_f32, exact fp32 products).  q,k,v,out: [B, S, H*D] with row stride `row_stride` floats

@@ -35,6 +35,13 @@ Two tiers of fixtures (the tier is stored in every file and in the manifest):
             smplx_decoder SMPLXDecoder.__init__/forward (src/models/smplx_decoder.py:40-145) with
                         rotation_6d_to_matrix / matrix_to_axis_angle := oracle/rotation.py (pytorch3d restatement)
 
+            stage1      (tier 1) ResnetBlockFC (src/models/triplane_net.py:16-58), TriplaneLearnablePositionalEmbedding
+                        (src/models/tokenizers.py), ImageFeature (src/models/image_feature.py:257-275);
+                        (tier 2) FeatureFusionNetwork (triplane_net.py:355-418, Attention injected as above) and
+                        SMPLXTriplaneEncoder.__init__/forward (:66-207) through a subclass that only replaces
+                        init_smplx_model / init_smplx_subdivider (absent smplx / pytorch3d) with ToyBody below, with
+                        torch_scatter's scatter_max / scatter_mean := oracle/triplane_net.py restatements
+
 Parameters are not stored: after a reference module is built, every entry of its state_dict is overwritten by
 `seeded_tensor(name, shape)` below, a pure function of the parameter's NAME; the tests rebuild the same values for
 the product modules (which must therefore expose the same names and shapes -- SURVEY Appendix B).
@@ -337,7 +344,7 @@ class OracleAttention(torch.nn.Module):
         self.to_out = torch.nn.ModuleList([torch.nn.Linear(inner, query_dim), torch.nn.Dropout(dropout)])
 
     def set_use_memory_efficient_attention_xformers(self, valid, attention_op=None):
-        assert not valid  # triplane_audio_net.py:139 passes enable_memory_efficient_attention=False
+        pass  # the audio net passes False (triplane_audio_net.py:139), stage 1 True (triplane_net.py:111,327): the same function
 
     def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None):
         assert attention_mask is None
@@ -422,6 +429,104 @@ def fixture_smplx_decoder(sd_mod):
                                     "(pytorch3d restatements; downstream LBS only sees Rodrigues(aa) = M)"]))
 
 
+class ToyBody(torch.nn.Module):
+    """INJECTED (tier 2) where the reference builds smplx.SMPLX (absent): a small deterministic body with the attributes
+    the stage-1 encoder touches (`faces`, `lbs_weights`, `v_template`) and the call signature of renderer.py:261-272;
+    `.vertices` = template + a fixed smooth function of the parameters.  Shared with the tests (helpers)."""
+
+    def __init__(self, num_verts=40, num_faces=60, seed=5):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        self.register_buffer("v_template", torch.randn(num_verts, 3, generator=g) * 0.5, persistent=False)
+        self.register_buffer("lbs_weights", torch.zeros(num_verts, 55), persistent=False)
+        self.faces = np.stack([torch.randperm(num_verts, generator=g)[:3].numpy() for _ in range(num_faces)]).astype(np.int64)
+        self.register_buffer("mix", torch.randn(185, num_verts * 3, generator=g) * 0.05, persistent=False)
+        self.num_verts = num_verts
+
+    def forward(self, global_orient, body_pose, betas, left_hand_pose, right_hand_pose, jaw_pose, leye_pose, reye_pose,
+                expression):
+        x = torch.cat([global_orient, body_pose, betas, left_hand_pose, right_hand_pose, jaw_pose, leye_pose, reye_pose,
+                       expression], dim=-1)
+        out = types.SimpleNamespace()
+        out.vertices = self.v_template[None] + torch.tanh(x @ self.mix[: x.shape[-1]]).reshape(x.shape[0], -1, 3)
+        return out
+
+
+def stage1_cfg():
+    return types.SimpleNamespace(triplane_resolution=4, triplane_feature_dim=32, radius=1.4, densify_smplx_verts=True,
+                                 subdivide_steps=0, sample_feature=False, upsample_triplane=False, upsample_factor=3,
+                                 predict_smplx_params=True, smpl_token_len=6, smpl_token_dim=32,
+                                 smplx_transformer_layers=1, smplx_transformer_head_dim=64, smplx_transformer_num_heads=1,
+                                 cross_transformer_layers=2, cross_transformer_head_dim=64, cross_transformer_num_heads=1,
+                                 image_feature_dim=1536, num_expression_coeffs=10, flat_hand_mean=True, device="cpu",
+                                 smplx_model_path=None)
+
+
+def fixture_stage1(tn, tok, imf, tr, sd_mod):
+    sys.path.insert(0, ROOT)
+    from oracle import rotation as orot, triplane_net as o_tn
+
+    # ---- tier 1
+    blk = tn.ResnetBlockFC(48, 32).eval()
+    p_blk = reseed_named(blk, "blocks.1.")
+    x_blk = rnd(71, 3, 20, 48)
+    emb = tok.TriplaneLearnablePositionalEmbedding(num_channels=8, plane_size=4).eval()
+    p_emb = reseed_named(emb, "triplane_tokenizer_geometry.")
+    cond = rnd(72, 2, 3, 8, 4, 4)
+    imfeat = imf.ImageFeature().eval()
+    p_imf = reseed_named(imfeat, "image_feature.")
+    rgb = rnd(73, 1, 1, 3, 8, 6)
+    tokens_in = rnd(74, 1, 1, 4096, 1536)  # regenerated from this seed by the tests (25 MB: not stored)
+    with torch.no_grad():
+        y_blk = blk(x_blk)
+        y_emb, y_plain = emb(batch_size=2, cond_embeddings=cond), emb(batch_size=1)
+        y_det = emb.detokenize(y_emb)
+        y_imf = imfeat(rgb, tokens_in)
+    t1 = save("stage1_parts", 1, ["src/models/triplane_net.py:16-58", "src/models/tokenizers.py", "src/models/image_feature.py:257-275"],
+              dict(x_blk=x_blk, y_blk=y_blk, cond=cond, y_emb=y_emb, y_plain=y_plain, y_det=y_det, rgb=rgb, y_imf=y_imf),
+              meta=dict(params_block=p_blk, params_embedding=p_emb, params_image_feature=p_imf, tokens_seed=74,
+                        tokens_shape=[1, 1, 4096, 1536]))
+    # ---- tier 2
+    cfg = stage1_cfg()
+    tr.Attention = OracleAttention
+    sd_mod.rotation_6d_to_matrix, sd_mod.matrix_to_axis_angle = orot.rotation_6d_to_matrix, orot.matrix_to_axis_angle
+    tn.scatter_max = lambda src, index, dim_size=None: (o_tn.scatter_max(src, index, dim_size), None)
+    tn.scatter_mean = lambda src, index, out=None: o_tn.scatter_mean(src, index, out.shape[-1])
+
+    class Encoder(tn.SMPLXTriplaneEncoder):  # only the two constructors of absent packages are replaced
+        def init_smplx_model(self):
+            return ToyBody()
+
+        def init_smplx_subdivider(self, subdivide_steps=2):
+            self.subdivider_list = []
+
+    dec = sd_mod.SMPLXDecoder(cfg).eval()
+    enc = Encoder(cfg, dec).eval()
+    fus = tn.FeatureFusionNetwork(cfg).eval()
+    shapes_enc = {k: list(v.shape) for k, v in enc.state_dict().items()}
+    enc.load_state_dict({k: seeded_tensor("smplx_triplane_encoder." + k, v.shape) for k, v in enc.state_dict().items()})
+    shapes_fus = {k: list(v.shape) for k, v in fus.state_dict().items()}
+    fus.load_state_dict({k: seeded_tensor("fusion_network." + k, v.shape) for k, v in fus.state_dict().items()})
+    with torch.no_grad():  # fc_1 is zero-initialised by the reference; seeded values make the blocks non-trivial (done above)
+        B, T, S = 1, 2, 16
+        img_tokens = rnd(75, B, T, S, cfg.image_feature_dim)
+        cam = {"intrinsic": torch.zeros(B, T, 3, 3), "extrinsic": torch.zeros(B, T, 4, 4)}
+        planes, smpl_tokens, pred = enc(cam, img_tokens, None, None)
+        gt = {k: v * 0.5 for k, v in pred.items()}
+        planes_gt, _, _ = enc(cam, img_tokens, gt, None)
+        fused, smpl_out = fus(planes, img_tokens, smpl_tokens)
+    arrays = dict(img_tokens=img_tokens, planes=planes, planes_gt=planes_gt, smpl_tokens=smpl_tokens, fused=fused,
+                  smpl_out=smpl_out)
+    arrays.update({"pred_" + k: v for k, v in pred.items()})
+    t2 = save("stage1", 2, ["src/models/triplane_net.py:66-207,209-244,355-418"], arrays,
+              meta=dict(cfg={k: v for k, v in vars(cfg).items()}, params_encoder=shapes_enc, params_fusion=shapes_fus,
+                        toy_body=dict(num_verts=40, num_faces=60, seed=5),
+                        injected=["smplx.SMPLX := ToyBody (init_smplx_model), pytorch3d subdivider := none",
+                                  "torch_scatter.scatter_max / scatter_mean := oracle/triplane_net.py",
+                                  "diffusers Attention := OracleAttention", "pytorch3d rot6d / axis-angle := oracle/rotation.py"]))
+    return [t1, t2]
+
+
 def main():
     if not os.path.isdir(os.path.join(REFERENCE, "src")):
         raise SystemExit(f"{REFERENCE}/src not found: this generator only runs in the build container")
@@ -434,13 +539,16 @@ def main():
     tan = importlib.import_module("src.models.triplane_audio_net")
     sd_mod = importlib.import_module("src.models.smplx_decoder")
     rd = importlib.import_module("src.models.renderer")
-    for m in (gu, mu, tr, tan, sd_mod, rd):
+    tn = importlib.import_module("src.models.triplane_net")
+    tok = importlib.import_module("src.models.tokenizers")
+    imf = importlib.import_module("src.models.image_feature")
+    for m in (gu, mu, tr, tan, sd_mod, rd, tn, tok, imf):
         assert os.path.realpath(m.__file__).startswith(os.path.realpath(REFERENCE)), m.__file__
     PHASE["name"] = "run"
     torch.manual_seed(0)
     torch.set_num_threads(1)  # bit-reproducible sums
     entries = [fixture_camera(gu), fixture_reducers(tan), fixture_feedforward(tr), fixture_triplane(rd, mu),
-               fixture_audio_net(tan, tr), fixture_smplx_decoder(sd_mod)]
+               fixture_audio_net(tan, tr), fixture_smplx_decoder(sd_mod)] + fixture_stage1(tn, tok, imf, tr, sd_mod)
     assert not RUN_EVENTS, f"a placeholder was used while producing fixtures: {RUN_EVENTS}"
     manifest = {"generator": "tests/golden/make_reference_golden.py", "reference": REFERENCE, "torch": torch.__version__,
                 "absent_packages_mapped_to_inert_placeholders": absent,

@@ -30,11 +30,57 @@ def test_host_logic_matches_oracle_on_cpu(frames, seconds, channels):
     assert np.abs(got - ref).max() < 1e-5
 
 
-def test_resampling_is_refused_loudly():
-    from audio_motion_avatar_amd.audio_frontend import extract_audio_features
+def test_resampler_known_answers():
+    """`resample` restates torchaudio.transforms.Resample's default (sinc + Hann, width 6, rolloff 0.99), which the
+    reference applies to non-16 kHz audio (dataset_speech_vid.py:40-42).  torchaudio is absent here: PARITY UNPINNED;
+    what can be checked are the properties the algorithm guarantees."""
+    import math
 
-    with pytest.raises(NotImplementedError, match="torchaudio"):
-        extract_audio_features(torch.zeros(1, 44100), 44100, 10, small_model())
+    from audio_motion_avatar_amd.audio_frontend import resample
+
+    x = torch.randn(2, 1000, generator=torch.Generator().manual_seed(0))
+    assert resample(x, 16000, 16000) is x
+    for orig, new in ((44100, 16000), (48000, 16000), (8000, 16000), (22050, 16000)):
+        n = orig  # one second
+        t = torch.arange(n, dtype=torch.float64) / orig
+        tone = torch.sin(2 * math.pi * 440.0 * t).float()[None]          # far below both Nyquist limits
+        y = resample(tone, orig, new)
+        assert y.shape == (1, math.ceil(n * new / orig))
+        tn = torch.arange(y.shape[1], dtype=torch.float64) / new
+        want = torch.sin(2 * math.pi * 440.0 * tn).float()
+        mid = slice(200, y.shape[1] - 200)                                # away from the zero-padded edges
+        assert (y[0, mid] - want[mid]).abs().max() < 2e-3, (orig, new)
+    # a tone above the target Nyquist frequency is removed, not aliased
+    t = torch.arange(44100, dtype=torch.float64) / 44100
+    high = torch.sin(2 * math.pi * 12000.0 * t).float()[None]
+    assert resample(high, 44100, 16000)[0, 200:-200].abs().max() < 2e-2
+    # linear and batch-shaped
+    a, b = torch.randn(3, 4410), torch.randn(3, 4410)
+    assert torch.allclose(resample(a + 2 * b, 44100, 16000), resample(a, 44100, 16000) + 2 * resample(b, 44100, 16000),
+                          atol=1e-5)
+    assert resample(torch.randn(2, 3, 441), 44100, 16000).shape == (2, 3, 160)
+
+
+def test_non_16k_audio_is_resampled_and_wav_files_load(tmp_path):
+    import struct
+    import wave
+
+    from audio_motion_avatar_amd.audio_frontend import extract_audio_features, load_wav, resample
+
+    sr, n = 22050, 22050
+    g = torch.Generator().manual_seed(3)
+    stereo = (torch.randn(2, n, generator=g) * 0.1).clamp(-0.99, 0.99)
+    pcm = (stereo * 32768.0).round().clamp(-32768, 32767).short()
+    with wave.open(str(tmp_path / "a.wav"), "wb") as w:
+        w.setnchannels(2), w.setsampwidth(2), w.setframerate(sr)
+        w.writeframes(pcm.T.contiguous().numpy().tobytes())
+    wav, got_sr = load_wav(str(tmp_path / "a.wav"))
+    assert got_sr == sr and wav.shape == (2, n) and (wav - pcm.float() / 32768.0).abs().max() == 0
+    model = small_model()
+    feats = extract_audio_features(wav, got_sr, 20, model)
+    same = extract_audio_features(resample(wav, sr, 16000), 16000, 20, model)
+    assert feats.shape == (20, 64) and torch.allclose(feats, same, atol=1e-6)
+    assert struct.calcsize("<h") == 2
 
 
 @pytest.mark.gpu

@@ -29,7 +29,7 @@ def test_manifest_says_no_placeholder_was_used_and_tiers_are_declared():
     assert m["placeholder_uses_during_run"] == 0
     tiers = {e["file"]: e["tier"] for e in m["fixtures"]}
     assert tiers == {"ref_camera.npz": 1, "ref_reducers.npz": 1, "ref_feedforward.npz": 1, "ref_triplane.npz": 1,
-                     "ref_audio_net.npz": 2, "ref_smplx_decoder.npz": 2}
+                     "ref_audio_net.npz": 2, "ref_smplx_decoder.npz": 2, "ref_stage1_parts.npz": 1, "ref_stage1.npz": 2}
     for need in ("diffusers", "pytorch3d", "smplx", "omegaconf", "diff_gaussian_rasterization"):
         assert need in m["absent_packages_mapped_to_inert_placeholders"]
     for e in m["fixtures"]:
@@ -174,3 +174,71 @@ def test_smplx_decoder_oracle_and_product_equal_the_reference_forward():
         mine = dec(a["tokens"])
     for k in want:
         close(mine[k], want[k], 5e-6, f"product smplx decoder[{k}]")
+
+
+def test_stage1_parts_oracle_and_product_equal_the_reference_classes():
+    """tier 1: ResnetBlockFC, TriplaneLearnablePositionalEmbedding, ImageFeature exactly as the reference ships them."""
+    from audio_motion_avatar_amd.triplane_net import ImageFeature, ResnetBlockFC, TriplaneLearnablePositionalEmbedding
+    from oracle import triplane_net as o_tn
+
+    a, meta, tier = ref_fixture("stage1_parts")
+    assert tier == 1
+    pb = seeded_params(meta["params_block"], "blocks.1.")
+    close(o_tn.resnet_block_fc({"b." + k: v for k, v in pb.items()}, "b.", a["x_blk"]), a["y_blk"], what="oracle ResnetBlockFC")
+    blk = ResnetBlockFC(48, 32).eval()
+    assert {k: list(v.shape) for k, v in blk.state_dict().items()} == meta["params_block"]
+    blk.load_state_dict(pb)
+    pe = seeded_params(meta["params_embedding"], "triplane_tokenizer_geometry.")
+    emb = TriplaneLearnablePositionalEmbedding(8, 4).eval()
+    emb.load_state_dict(pe)
+    pi = seeded_params(meta["params_image_feature"], "image_feature.")
+    imf = ImageFeature().eval()
+    assert {k: list(v.shape) for k, v in imf.state_dict().items()} == meta["params_image_feature"]
+    imf.load_state_dict(pi)
+    tokens = torch.randn(*meta["tokens_shape"], generator=torch.Generator().manual_seed(meta["tokens_seed"]))
+    with torch.no_grad():
+        close(blk(a["x_blk"]), a["y_blk"], what="product ResnetBlockFC")
+        close(emb(batch_size=2, cond_embeddings=a["cond"]), a["y_emb"], what="product tokenizer")
+        close(emb(batch_size=1), a["y_plain"], what="product tokenizer (no condition)")
+        close(emb.detokenize(a["y_emb"]), a["y_det"], what="product detokenize")
+        close(imf(a["rgb"], tokens), a["y_imf"], 5e-6, "product ImageFeature")
+        close(o_tn.image_feature({"i." + k: v for k, v in pi.items()}, "i.", a["rgb"], tokens), a["y_imf"], 5e-6,
+              "oracle ImageFeature")
+
+
+def test_stage1_oracle_equals_the_reference_encoder_and_fusion_network():
+    """tier 2: SMPLXTriplaneEncoder.__init__/forward and FeatureFusionNetwork as the reference ships them, with the absent
+    smplx / torch_scatter / diffusers / pytorch3d pieces injected (generator docstring).  Pins the point network's
+    wiring (input order, block / pool sequence), the cell index formula, plane order and reshape, the SMPL-X predictor
+    and the token concatenation / split of the fusion network."""
+    from helpers import toy_body
+    from oracle import smplx_decoder as o_dec, transformer as o_tr, triplane_net as o_tn
+
+    a, meta, tier = ref_fixture("stage1")
+    assert tier == 2
+    cfg = meta["cfg"]
+    pe = {"e." + k: v for k, v in seeded_params(meta["params_encoder"], "smplx_triplane_encoder.").items()}
+    pf = {"f." + k: v for k, v in seeded_params(meta["params_fusion"], "fusion_network.").items()}
+    B, T = a["img_tokens"].shape[:2]
+    # SMPL-X predictor (:209-224)
+    query = pe["e.smpl_tokens"].unsqueeze(0).repeat(B * T, 1, 1)
+    tokens = o_tr.transformer1d(pe, "e.cross_attn.", query, a["img_tokens"].reshape(B * T, *a["img_tokens"].shape[2:]),
+                                cfg["smplx_transformer_layers"], cfg["smplx_transformer_num_heads"])
+    close(tokens, a["smpl_tokens"], 5e-6, "oracle smpl predictor tokens")
+    pred = o_dec.smplx_decoder_forward({k.replace("e.smpl_decoder.", "smpl_decoder."): v for k, v in pe.items()}, tokens)
+    for k, v in pred.items():
+        close(v.reshape(a["pred_" + k].shape), a["pred_" + k], 5e-6, f"oracle predicted {k}")
+    # point network on the toy body's vertices + face centres
+    body = toy_body(**meta["toy_body"])
+    for params, want in ((pred, a["planes"]), ({k: v * 0.5 for k, v in pred.items()}, a["planes_gt"])):
+        flat = {k: v.reshape(B * T, -1) for k, v in params.items()}
+        verts = body(**{k: flat[k] for k in ("global_orient", "body_pose", "betas", "left_hand_pose", "right_hand_pose",
+                                             "jaw_pose", "leye_pose", "reye_pose", "expression")}).vertices
+        verts = torch.cat([verts, verts[:, torch.as_tensor(body.faces)].mean(dim=2)], dim=1)
+        emb = pe["e.vertex_emb.weight"].unsqueeze(0).expand(B * T, -1, -1)
+        planes = o_tn.encoder_forward(pe, "e.", verts, emb, cfg["radius"], cfg["triplane_resolution"])
+        close(planes.reshape(want.shape), want, 5e-6, "oracle geometry triplanes")
+    fused, smpl_out = o_tn.fusion_forward(pf, "f.", a["planes"], a["img_tokens"], a["smpl_tokens"],
+                                          cfg["cross_transformer_layers"], cfg["cross_transformer_num_heads"])
+    close(fused, a["fused"], 5e-6, "oracle fused triplane tokens")
+    close(smpl_out, a["smpl_out"], 5e-6, "oracle fused smpl tokens")
