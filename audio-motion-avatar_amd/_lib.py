@@ -95,6 +95,24 @@ SIGNATURES = {
     "amav_points_project": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                            c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_float, c_float_p,
                                            ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "amav_cloud_voxelize": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, c_float_p, ctypes.c_void_p, ctypes.c_float,
+                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "amav_cloud_codes": (ctypes.c_int, [ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                        ctypes.c_void_p, ctypes.c_void_p]),
+    "amav_cloud_neighbors": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                            ctypes.c_void_p, ctypes.c_void_p]),
+    "amav_subm_gather": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, c_float_p, ctypes.c_void_p,
+                                        c_float_p, c_float_p, ctypes.c_void_p]),
+    "amav_patch_attention": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_float_p,
+                                            ctypes.c_void_p, ctypes.c_void_p, c_float_p, ctypes.c_float,
+                                            ctypes.c_void_p]),
+    "amav_cluster_max": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, c_float_p, ctypes.c_void_p, ctypes.c_void_p,
+                                        c_float_p, c_float_p, c_float_p, ctypes.c_void_p]),
+    "amav_bn_gelu": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, c_float_p, c_float_p, c_float_p, c_float_p,
+                                    ctypes.c_void_p]),
+    "amav_unpool_merge": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, c_float_p, c_float_p, c_float_p, c_float_p,
+                                         ctypes.c_void_p, c_float_p, c_float_p, ctypes.c_void_p]),
     "amav_lbs_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.POINTER(BodyTables)]),
     "amav_lbs_forward": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(BodyTables), c_float_p, c_float_p, c_float_p,
                                         c_float_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),

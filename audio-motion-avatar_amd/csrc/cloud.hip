@@ -1,0 +1,496 @@
+// Point refiner (second half): the sparse / serialised pieces of the reference's
+// PointTransformerV3 (src/models/point_transformer/pointtransformer_v3.py, point_encoder.py:25-40, called from
+// src/models/renderer.py:143-151) for a batch of CLOUDS (one per frame), deterministic.
+//
+// The reference leans on spconv (hash-table submanifold convolution), torch_scatter (segment_csr) and, optionally,
+// flash_attn; none has a ROCm build.  What replaces them here:
+//
+//   amav_cloud_voxelize    grid = floor(res * p) - per-cloud minimum, serialisation depth per cloud      (point_encoder.py:33,
+//                          pointtransformer_v3.py:98-101; origin / depth per cloud: DESIGN.md section 4.2)
+//   amav_cloud_codes       the four serialisation keys (z, z-trans, hilbert, hilbert-trans) of every point, as
+//                          (cloud << 48 | code) so that ONE stable sort orders all clouds    (serialization/*.py)
+//   amav_cloud_neighbors   [n, k^3] table of the rows a submanifold convolution gathers: binary search of the
+//                          neighbour voxel's z-order key in the cloud's sorted key run (no hash table: the sorted run
+//                          is already there, and "first row of the run of equal keys" is a reproducible choice for
+//                          voxels that hold several points)                                     (spconv SubMConv3d)
+//   amav_subm_gather       out[i] = bias + sum over taps of Y[nbr[i][tap]][tap][:] where Y = feat x W_all is ONE dense
+//                          GEMM over all taps (taps summed in tap order: fixed evaluation order)
+//   amav_patch_attention   softmax(Q K^T / sqrt(d)) V inside patches of <= 512 consecutive points of a serialised
+//                          order, rows gathered through the order; fp32 MFMA, online softmax   (SerializedAttention)
+//   amav_cluster_max       per-cluster channel maximum + BatchNorm(eval) + GELU                 (SerializedPooling)
+//   amav_bn_gelu           BatchNorm(eval) + GELU                                                (Embedding, Unpooling)
+//   amav_unpool_merge      skip = GELU(BN(x)); sum = skip + up[cluster]                        (SerializedUnpooling)
+#include <climits>
+
+#include "amav_common.h"
+
+namespace amav {
+namespace cloud {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+
+__device__ __forceinline__ float gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// ---- voxelize -----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bounds_init_kernel(int clouds, int *__restrict__ bounds) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < clouds * 6) bounds[i] = (i % 6) < 3 ? INT_MAX : INT_MIN;
+}
+
+__device__ __forceinline__ int wave_min(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__global__ __launch_bounds__(256) void bounds_kernel(long long n, const float *__restrict__ points,
+                                                     const int *__restrict__ cloud_of, float res,
+                                                     int *__restrict__ bounds) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < n;
+    const long long j = live ? i : n - 1;
+    const int c = cloud_of[j];
+    const int gx = (int)floorf(points[3 * j] * res), gy = (int)floorf(points[3 * j + 1] * res),
+              gz = (int)floorf(points[3 * j + 2] * res);
+    const int c0 = __builtin_amdgcn_readfirstlane(c);
+    if (__all(c == c0)) {  // the usual case: a wave lies inside one cloud -> six atomics per wave
+        const int a = wave_min(gx), b = wave_min(gy), d = wave_min(gz), e = wave_max(gx), f = wave_max(gy), g = wave_max(gz);
+        if ((threadIdx.x & 63) == 0) {
+            int *bd = bounds + 6 * c0;
+            atomicMin(bd, a), atomicMin(bd + 1, b), atomicMin(bd + 2, d);
+            atomicMax(bd + 3, e), atomicMax(bd + 4, f), atomicMax(bd + 5, g);
+        }
+    } else {
+        int *bd = bounds + 6 * c;
+        atomicMin(bd, gx), atomicMin(bd + 1, gy), atomicMin(bd + 2, gz);
+        atomicMax(bd + 3, gx), atomicMax(bd + 4, gy), atomicMax(bd + 5, gz);
+    }
+}
+
+__global__ __launch_bounds__(256) void grid_kernel(long long n, int clouds, const float *__restrict__ points,
+                                                   const int *__restrict__ cloud_of, float res,
+                                                   const int *__restrict__ bounds, int *__restrict__ grid,
+                                                   int *__restrict__ depth) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < clouds) {
+        const int *bd = bounds + 6 * i;
+        const int ext = max(max(bd[3] - bd[0], bd[4] - bd[1]), bd[5] - bd[2]);
+        depth[i] = ext > 0 ? 32 - __clz(ext) : 0;  // int.bit_length() of the largest grid coordinate
+    }
+    if (i >= n) return;
+    const int *bd = bounds + 6 * cloud_of[i];
+    grid[3 * i] = (int)floorf(points[3 * i] * res) - bd[0];
+    grid[3 * i + 1] = (int)floorf(points[3 * i + 1] * res) - bd[1];
+    grid[3 * i + 2] = (int)floorf(points[3 * i + 2] * res) - bd[2];
+}
+
+// ---- serialisation keys ---------------------------------------------------------------------------------------------
+// bit i of v -> bit 3 i (16 bits in, 46 bits out)
+__device__ __forceinline__ unsigned long long spread3(unsigned int v) {
+    unsigned long long x = v & 0xffffu;
+    x = (x | (x << 16)) & 0x0000ff0000ffULL;
+    x = (x | (x << 8)) & 0x00f00f00f00fULL;
+    x = (x | (x << 4)) & 0x0c30c30c30c3ULL;
+    x = (x | (x << 2)) & 0x249249249249ULL;
+    return x;
+}
+
+// z_order.py:42-52: x -> bit 3i+2, y -> 3i+1, z -> 3i
+__device__ __forceinline__ unsigned long long z_code(unsigned int x, unsigned int y, unsigned int z) {
+    return (spread3(x) << 2) | (spread3(y) << 1) | spread3(z);
+}
+
+// hilbert.py:93-190 = Skilling's AxesToTranspose, most significant bit first, then the Gray decode of the
+// interleaved bits (axis 0 most significant inside a triple)
+__device__ __forceinline__ unsigned long long hilbert_code(unsigned int x0, unsigned int x1, unsigned int x2, int depth) {
+    for (int bit = depth - 1; bit > 0; --bit) {  // Q = 1 << bit; the pass with Q = 1 has no lower bits to touch
+        const unsigned int Q = 1u << bit, P = Q - 1;
+        unsigned int t;
+        if (x0 & Q) x0 ^= P;
+        if (x1 & Q) x0 ^= P; else { t = (x0 ^ x1) & P; x0 ^= t; x1 ^= t; }
+        if (x2 & Q) x0 ^= P; else { t = (x0 ^ x2) & P; x0 ^= t; x2 ^= t; }
+    }
+    unsigned long long g = z_code(x0, x1, x2);
+    g ^= g >> 1, g ^= g >> 2, g ^= g >> 4, g ^= g >> 8, g ^= g >> 16, g ^= g >> 32;
+    return g;
+}
+
+__global__ __launch_bounds__(256) void codes_kernel(long long n, const int *__restrict__ grid,
+                                                    const int *__restrict__ cloud_of, const int *__restrict__ cloud_depth,
+                                                    long long *__restrict__ keys) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = cloud_of[i], depth = cloud_depth[c];
+    const unsigned int mask = depth >= 16 ? 0xffffu : ((1u << depth) - 1u);
+    const unsigned int x = grid[3 * i] & mask, y = grid[3 * i + 1] & mask, z = grid[3 * i + 2] & mask;
+    const long long hi = (long long)c << 48;
+    keys[i] = hi | (long long)z_code(x, y, z);
+    keys[n + i] = hi | (long long)z_code(y, x, z);
+    keys[2 * n + i] = hi | (long long)hilbert_code(x, y, z, depth);
+    keys[3 * n + i] = hi | (long long)hilbert_code(y, x, z, depth);
+}
+
+// ---- neighbour table --------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void neighbors_kernel(long long n, int ksize, const int *__restrict__ grid,
+                                                        const int *__restrict__ cloud_of,
+                                                        const int *__restrict__ cloud_depth,
+                                                        const int *__restrict__ cloud_start,
+                                                        const long long *__restrict__ sorted_keys,
+                                                        const long long *__restrict__ order, int *__restrict__ nbr) {
+    const int taps = ksize * ksize * ksize;
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n * taps) return;
+    const long long i = gid / taps;
+    const int t = (int)(gid - i * taps), r = ksize / 2;
+    const int da = t / (ksize * ksize) - r, db = (t / ksize) % ksize - r, dc = t % ksize - r;
+    if ((da | db | dc) == 0) {  // the centre tap is the point itself, also where a voxel holds several points
+        nbr[gid] = (int)i;
+        return;
+    }
+    const int c = cloud_of[i], depth = cloud_depth[c];
+    const int x = grid[3 * i] + da, y = grid[3 * i + 1] + db, z = grid[3 * i + 2] + dc;
+    const int lim = depth >= 16 ? 65536 : (1 << depth);
+    int found = -1;
+    if (x >= 0 && y >= 0 && z >= 0 && x < lim && y < lim && z < lim) {
+        const long long key = ((long long)c << 48) | (long long)z_code(x, y, z);
+        int lo = cloud_start[c], hi = cloud_start[c + 1];
+        const int end = hi;
+        while (lo < hi) {  // lower bound: first sorted position with key >= target
+            const int mid = (lo + hi) >> 1;
+            if (sorted_keys[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        if (lo < end && sorted_keys[lo] == key) found = (int)order[lo];  // stable sort: the voxel's lowest row
+    }
+    nbr[gid] = found;
+}
+
+// ---- gather-sum of the per-tap products ----------------------------------------------------------------------------------
+// Y [n][taps][cout]; one thread per (row, 4 channels); taps in ascending order
+__global__ __launch_bounds__(256) void subm_gather_kernel(long long n, int taps, int cout4, const float4 *__restrict__ Y,
+                                                          const int *__restrict__ nbr, const float4 *__restrict__ bias,
+                                                          float4 *__restrict__ out) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n * cout4) return;
+    const long long i = gid / cout4;
+    const int c = (int)(gid - i * cout4);
+    float4 acc = bias ? bias[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int *nb = nbr + i * taps;
+    const long long row4 = (long long)taps * cout4;
+#pragma unroll 4
+    for (int t = 0; t < taps; ++t) {
+        const int j = nb[t];
+        if (j >= 0) {
+            const float4 y = Y[j * row4 + (long long)t * cout4 + c];
+            acc.x += y.x, acc.y += y.y, acc.z += y.z, acc.w += y.w;
+        }
+    }
+    out[gid] = acc;
+}
+
+// ---- patch attention --------------------------------------------------------------------------------------------------
+// desc[patch] = {first sorted position, K (keys = queries of the patch), own (leading positions that are stored), 0}.
+// Position j of the patch is sorted position first + j, or first + j - K for j >= own: the tail of a cloud's last,
+// incomplete patch is filled with the same slots of the patch before it (pointtransformer_v3.py:419-432); those
+// borrowed slots take part as keys and their query results are dropped (the `unpad` gather at :462,493).
+// One workgroup = 128 queries of one (patch, head); S^T = K Q^T and O^T = V^T P^T on v_mfma_f32_32x32x2_f32 with the
+// probabilities kept in registers (layout notes: attention.hip).
+template <int D>
+__global__ __launch_bounds__(256) void patch_attention_kernel(const float *__restrict__ qkv,
+                                                              const long long *__restrict__ order,
+                                                              const int4 *__restrict__ desc, float *__restrict__ out,
+                                                              int C, float scale_log2e) {
+    constexpr int DV = D < 32 ? 32 : D;  // width of the V tile (zero padded: the MFMA produces 32 rows of O^T)
+    constexpr int NO = DV / 32;
+    constexpr int kLdk = 65;
+    __shared__ float Kt[D * kLdk];  // [d][key]
+    __shared__ float Vs[64 * DV];   // [key][d]
+    __shared__ long long rows[64];  // qkv row of every key of the tile
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int c = lane & 31, hh = lane >> 5;
+    const int head = blockIdx.y;
+    const int4 pd = desc[blockIdx.z];
+    const int first = pd.x, K = pd.y, own = pd.z;
+    if ((int)blockIdx.x * 128 >= K) return;  // uniform over the workgroup
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    auto row_of = [&](int j) -> long long {
+        j = min(j, K - 1);
+        return order[first + j - (j >= own ? K : 0)];
+    };
+    const long long stride = 3LL * C;
+
+    float Qr[D / 2];
+    const long long qrow = row_of(q0 + c);
+    {
+        const float *qp = qkv + qrow * stride + head * D;
+#pragma unroll
+        for (int s = 0; s < D / 2; ++s) {
+            const float2 t = *reinterpret_cast<const float2 *>(qp + 2 * s);
+            Qr[s] = (hh ? t.y : t.x) * scale_log2e;
+        }
+    }
+    if (D < 32) {  // columns D..31 of V stay zero for the whole sweep
+        for (int t = tid; t < 64 * (DV - D); t += 256) Vs[(t / (DV - D)) * DV + D + t % (DV - D)] = 0.f;
+    }
+
+    f32x16 O[NO];
+#pragma unroll
+    for (int a = 0; a < NO; ++a)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) O[a][t] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;
+
+    const int ntiles = (K + 63) / 64;
+    for (int kt = 0; kt < ntiles; ++kt) {
+        if (tid < 64) rows[tid] = row_of(kt * 64 + tid);
+        __syncthreads();
+        constexpr int kQuads = 64 * D / 4;  // float4s per matrix tile
+#pragma unroll
+        for (int i = 0; i < (kQuads + 255) / 256; ++i) {
+            const int t = tid + 256 * i;
+            if (t < kQuads) {
+                const int key = t / (D / 4), d4 = (t % (D / 4)) * 4;
+                const float *kp = qkv + rows[key] * stride + C + head * D + d4;
+                const float4 kv = *reinterpret_cast<const float4 *>(kp);
+                const float4 vv = *reinterpret_cast<const float4 *>(kp + C);
+                Kt[(d4 + 0) * kLdk + key] = kv.x;
+                Kt[(d4 + 1) * kLdk + key] = kv.y;
+                Kt[(d4 + 2) * kLdk + key] = kv.z;
+                Kt[(d4 + 3) * kLdk + key] = kv.w;
+                *reinterpret_cast<float4 *>(&Vs[key * DV + d4]) = vv;
+            }
+        }
+        __syncthreads();
+
+        f32x16 S0, S1;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) S0[t] = 0.f, S1[t] = 0.f;
+#pragma unroll
+        for (int s = 0; s < D / 2; ++s) {
+            const float a0 = Kt[(2 * s + hh) * kLdk + c], a1 = Kt[(2 * s + hh) * kLdk + 32 + c];
+            S0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, Qr[s], S0, 0, 0, 0);
+            S1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, Qr[s], S1, 0, 0, 0);
+        }
+        if ((kt + 1) * 64 > K) {  // accumulator register t of key half kb: key kt*64 + 32 kb + (t&3) + 8 (t>>2) + 4 hh
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int kk = kt * 64 + (t & 3) + 8 * (t >> 2) + 4 * hh;
+                if (kk >= K) S0[t] = -1e30f;
+                if (kk + 32 >= K) S1[t] = -1e30f;
+            }
+        }
+        float mx = S0[0];
+#pragma unroll
+        for (int t = 1; t < 16; ++t) mx = fmaxf(mx, S0[t]);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) mx = fmaxf(mx, S1[t]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float corr = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+#pragma unroll
+        for (int a = 0; a < NO; ++a)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) O[a][t] *= corr;
+
+        float psum = 0.f;
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            const float p = __builtin_amdgcn_exp2f((u < 16 ? S0[u] : S1[u - 16]) - m_new);
+            psum += p;
+            const int vr = ((u >> 4) * 32 + (u & 3) + 8 * ((u & 15) >> 2) + 4 * hh) * DV + c;
+#pragma unroll
+            for (int a = 0; a < NO; ++a) O[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[vr + 32 * a], p, O[a], 0, 0, 0);
+        }
+        l_run = l_run * corr + psum;
+        __syncthreads();
+    }
+
+    const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32, 64));
+    if (q0 + c < own) {  // own <= K; the slots behind it are another patch's points
+        float *orow = out + qrow * C + head * D;
+#pragma unroll
+        for (int a = 0; a < NO; ++a)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {  // registers 4g..4g+3 are the consecutive d = 32 a + 8 g + 4 hh + (0..3)
+                const int d = 32 * a + 8 * g + 4 * hh;
+                if (d < D)
+                    *reinterpret_cast<float4 *>(orow + d) = make_float4(O[a][4 * g] * inv, O[a][4 * g + 1] * inv,
+                                                                        O[a][4 * g + 2] * inv, O[a][4 * g + 3] * inv);
+            }
+    }
+}
+
+// ---- pooling / normalisation ------------------------------------------------------------------------------------------
+// one wave per cluster: max over rows members[seg[j] .. seg[j+1]) of x, then y = gelu(x * scale + shift)
+__global__ __launch_bounds__(256) void cluster_max_kernel(long long clusters, int C4, const float4 *__restrict__ x,
+                                                          const long long *__restrict__ members,
+                                                          const long long *__restrict__ seg,
+                                                          const float4 *__restrict__ scale, const float4 *__restrict__ shift,
+                                                          float4 *__restrict__ out) {
+    const long long j = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= clusters) return;
+    const int lane = threadIdx.x & 63;
+    const long long beg = seg[j], end = seg[j + 1];
+    for (int c = lane; c < C4; c += 64) {
+        float4 m = x[members[beg] * C4 + c];
+        for (long long r = beg + 1; r < end; ++r) {
+            const float4 v = x[members[r] * C4 + c];
+            m.x = fmaxf(m.x, v.x), m.y = fmaxf(m.y, v.y), m.z = fmaxf(m.z, v.z), m.w = fmaxf(m.w, v.w);
+        }
+        const float4 s = scale[c], b = shift[c];
+        out[j * C4 + c] = make_float4(gelu(m.x * s.x + b.x), gelu(m.y * s.y + b.y), gelu(m.z * s.z + b.z),
+                                      gelu(m.w * s.w + b.w));
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_gelu_kernel(long long quads, int C4, const float4 *__restrict__ x,
+                                                      const float4 *__restrict__ scale, const float4 *__restrict__ shift,
+                                                      float4 *__restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= quads) return;
+    const int c = (int)(i % C4);
+    const float4 v = x[i], s = scale[c], b = shift[c];
+    out[i] = make_float4(gelu(v.x * s.x + b.x), gelu(v.y * s.y + b.y), gelu(v.z * s.z + b.z), gelu(v.w * s.w + b.w));
+}
+
+__global__ __launch_bounds__(256) void unpool_merge_kernel(long long quads, int C4, const float4 *__restrict__ x,
+                                                           const float4 *__restrict__ scale, const float4 *__restrict__ shift,
+                                                           const float4 *__restrict__ up, const long long *__restrict__ cluster,
+                                                           float4 *__restrict__ skip, float4 *__restrict__ sum) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= quads) return;
+    const long long row = i / C4;
+    const int c = (int)(i - row * C4);
+    const float4 v = x[i], s = scale[c], b = shift[c];
+    const float4 k = make_float4(gelu(v.x * s.x + b.x), gelu(v.y * s.y + b.y), gelu(v.z * s.z + b.z), gelu(v.w * s.w + b.w));
+    const float4 u = up[cluster[row] * C4 + c];
+    skip[i] = k;
+    sum[i] = make_float4(k.x + u.x, k.y + u.y, k.z + u.z, k.w + u.w);
+}
+
+}  // namespace cloud
+}  // namespace amav
+
+using namespace amav;
+
+static inline unsigned blocks_for(long long threads) { return (unsigned)((threads + 255) / 256); }
+static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+extern "C" int amav_cloud_voxelize(int64_t n, int clouds, const float *points, const int32_t *cloud_of, float resolution,
+                                   int32_t *grid, int32_t *cloud_depth, int32_t *bounds, void *stream_) {
+    AMAV_REQUIRE(n > 0 && clouds > 0 && clouds < 32768, "amav_cloud_voxelize: bad sizes n=%lld clouds=%d", (long long)n, clouds);
+    AMAV_REQUIRE(points && cloud_of && grid && cloud_depth && bounds, "amav_cloud_voxelize: NULL pointer");
+    AMAV_REQUIRE(resolution > 0.f, "amav_cloud_voxelize: resolution must be positive");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    cloud::bounds_init_kernel<<<blocks_for(clouds * 6), 256, 0, stream>>>(clouds, bounds);
+    cloud::bounds_kernel<<<blocks_for(n), 256, 0, stream>>>(n, points, cloud_of, resolution, bounds);
+    cloud::grid_kernel<<<blocks_for(n > clouds ? n : clouds), 256, 0, stream>>>(n, clouds, points, cloud_of, resolution, bounds,
+                                                                             grid, cloud_depth);
+    return check_launch("amav_cloud_voxelize");
+}
+
+extern "C" int amav_cloud_codes(int64_t n, const int32_t *grid, const int32_t *cloud_of, const int32_t *cloud_depth,
+                                int64_t *keys, void *stream) {
+    AMAV_REQUIRE(n > 0, "amav_cloud_codes: bad size n=%lld", (long long)n);
+    AMAV_REQUIRE(grid && cloud_of && cloud_depth && keys, "amav_cloud_codes: NULL pointer");
+    cloud::codes_kernel<<<blocks_for(n), 256, 0, static_cast<hipStream_t>(stream)>>>(
+        n, grid, cloud_of, cloud_depth, reinterpret_cast<long long *>(keys));
+    return check_launch("amav_cloud_codes");
+}
+
+extern "C" int amav_cloud_neighbors(int64_t n, int ksize, const int32_t *grid, const int32_t *cloud_of,
+                                    const int32_t *cloud_depth, const int32_t *cloud_start, const int64_t *sorted_keys,
+                                    const int64_t *order, int32_t *nbr, void *stream) {
+    AMAV_REQUIRE(n > 0 && n < INT_MAX && (ksize == 3 || ksize == 5), "amav_cloud_neighbors: bad sizes n=%lld ksize=%d",
+                 (long long)n, ksize);
+    AMAV_REQUIRE(grid && cloud_of && cloud_depth && cloud_start && sorted_keys && order && nbr,
+                 "amav_cloud_neighbors: NULL pointer");
+    const long long threads = (long long)n * ksize * ksize * ksize;
+    cloud::neighbors_kernel<<<blocks_for(threads), 256, 0, static_cast<hipStream_t>(stream)>>>(
+        n, ksize, grid, cloud_of, cloud_depth, cloud_start, reinterpret_cast<const long long *>(sorted_keys),
+        reinterpret_cast<const long long *>(order), nbr);
+    return check_launch("amav_cloud_neighbors");
+}
+
+extern "C" int amav_subm_gather(int64_t n, int taps, int cout, const float *products, const int32_t *nbr,
+                                const float *bias, float *out, void *stream) {
+    AMAV_REQUIRE(n > 0 && taps > 0 && cout > 0 && cout % 4 == 0, "amav_subm_gather: bad sizes n=%lld taps=%d cout=%d",
+                 (long long)n, taps, cout);
+    AMAV_REQUIRE(products && nbr && out, "amav_subm_gather: NULL pointer");
+    AMAV_REQUIRE(aligned16(products) && aligned16(out) && (!bias || aligned16(bias)), "amav_subm_gather: buffers must be 16-byte aligned");
+    cloud::subm_gather_kernel<<<blocks_for((long long)n * (cout / 4)), 256, 0, static_cast<hipStream_t>(stream)>>>(
+        n, taps, cout / 4, reinterpret_cast<const float4 *>(products), nbr, reinterpret_cast<const float4 *>(bias),
+        reinterpret_cast<float4 *>(out));
+    return check_launch("amav_subm_gather");
+}
+
+extern "C" int amav_patch_attention(int patches, int max_patch, int heads, int head_dim, const float *qkv,
+                                    const int64_t *order, const int32_t *patch_desc, float *out, float scale,
+                                    void *stream_) {
+    AMAV_REQUIRE(patches > 0 && patches <= 65535 && heads > 0 && heads <= 65535 && max_patch > 0,
+                 "amav_patch_attention: bad sizes patches=%d heads=%d max_patch=%d", patches, heads, max_patch);
+    AMAV_REQUIRE(head_dim == 16 || head_dim == 32 || head_dim == 64, "amav_patch_attention: head_dim %d (16, 32, 64 are built)",
+                 head_dim);
+    AMAV_REQUIRE(qkv && order && patch_desc && out, "amav_patch_attention: NULL pointer");
+    AMAV_REQUIRE(aligned16(qkv) && aligned16(out) && aligned16(patch_desc), "amav_patch_attention: buffers must be 16-byte aligned");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const dim3 grid((unsigned)((max_patch + 127) / 128), (unsigned)heads, (unsigned)patches);
+    const int C = heads * head_dim;
+    const float sl = scale * 1.4426950408889634f;
+    const long long *ord = reinterpret_cast<const long long *>(order);
+    const int4 *pd = reinterpret_cast<const int4 *>(patch_desc);
+    if (head_dim == 16)
+        cloud::patch_attention_kernel<16><<<grid, 256, 0, stream>>>(qkv, ord, pd, out, C, sl);
+    else if (head_dim == 32)
+        cloud::patch_attention_kernel<32><<<grid, 256, 0, stream>>>(qkv, ord, pd, out, C, sl);
+    else
+        cloud::patch_attention_kernel<64><<<grid, 256, 0, stream>>>(qkv, ord, pd, out, C, sl);
+    return check_launch("amav_patch_attention");
+}
+
+extern "C" int amav_cluster_max(int64_t clusters, int channels, const float *x, const int64_t *members, const int64_t *seg,
+                                const float *scale, const float *shift, float *out, void *stream) {
+    AMAV_REQUIRE(clusters > 0 && channels > 0 && channels % 4 == 0, "amav_cluster_max: bad sizes clusters=%lld channels=%d",
+                 (long long)clusters, channels);
+    AMAV_REQUIRE(x && members && seg && scale && shift && out, "amav_cluster_max: NULL pointer");
+    AMAV_REQUIRE(aligned16(x) && aligned16(scale) && aligned16(shift) && aligned16(out), "amav_cluster_max: buffers must be 16-byte aligned");
+    cloud::cluster_max_kernel<<<(unsigned)((clusters + 3) / 4), 256, 0, static_cast<hipStream_t>(stream)>>>(
+        clusters, channels / 4, reinterpret_cast<const float4 *>(x), reinterpret_cast<const long long *>(members),
+        reinterpret_cast<const long long *>(seg), reinterpret_cast<const float4 *>(scale),
+        reinterpret_cast<const float4 *>(shift), reinterpret_cast<float4 *>(out));
+    return check_launch("amav_cluster_max");
+}
+
+extern "C" int amav_bn_gelu(int64_t rows, int channels, const float *x, const float *scale, const float *shift, float *out,
+                            void *stream) {
+    AMAV_REQUIRE(rows > 0 && channels > 0 && channels % 4 == 0, "amav_bn_gelu: bad sizes rows=%lld channels=%d",
+                 (long long)rows, channels);
+    AMAV_REQUIRE(x && scale && shift && out, "amav_bn_gelu: NULL pointer");
+    AMAV_REQUIRE(aligned16(x) && aligned16(scale) && aligned16(shift) && aligned16(out), "amav_bn_gelu: buffers must be 16-byte aligned");
+    const long long quads = (long long)rows * (channels / 4);
+    cloud::bn_gelu_kernel<<<blocks_for(quads), 256, 0, static_cast<hipStream_t>(stream)>>>(
+        quads, channels / 4, reinterpret_cast<const float4 *>(x), reinterpret_cast<const float4 *>(scale),
+        reinterpret_cast<const float4 *>(shift), reinterpret_cast<float4 *>(out));
+    return check_launch("amav_bn_gelu");
+}
+
+extern "C" int amav_unpool_merge(int64_t rows, int channels, const float *x, const float *scale, const float *shift,
+                                 const float *up, const int64_t *cluster, float *skip, float *sum, void *stream) {
+    AMAV_REQUIRE(rows > 0 && channels > 0 && channels % 4 == 0, "amav_unpool_merge: bad sizes rows=%lld channels=%d",
+                 (long long)rows, channels);
+    AMAV_REQUIRE(x && scale && shift && up && cluster && skip && sum, "amav_unpool_merge: NULL pointer");
+    AMAV_REQUIRE(aligned16(x) && aligned16(scale) && aligned16(shift) && aligned16(up) && aligned16(skip) && aligned16(sum),
+                 "amav_unpool_merge: buffers must be 16-byte aligned");
+    const long long quads = (long long)rows * (channels / 4);
+    cloud::unpool_merge_kernel<<<blocks_for(quads), 256, 0, static_cast<hipStream_t>(stream)>>>(
+        quads, channels / 4, reinterpret_cast<const float4 *>(x), reinterpret_cast<const float4 *>(scale),
+        reinterpret_cast<const float4 *>(shift), reinterpret_cast<const float4 *>(up),
+        reinterpret_cast<const long long *>(cluster), reinterpret_cast<float4 *>(skip), reinterpret_cast<float4 *>(sum));
+    return check_launch("amav_unpool_merge");
+}

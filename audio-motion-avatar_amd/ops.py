@@ -590,3 +590,111 @@ def _shaped(t, name, shape):
     if tuple(t.shape) != tuple(shape) or not t.is_contiguous():
         raise AmavError(f"{name}: expected a contiguous tensor of shape {tuple(shape)}, got {tuple(t.shape)}")
     return t
+
+
+# -------------------------------------------------------------------------------------------------- point refiner
+def cloud_voxelize(points, cloud_of, clouds, resolution=100.0):
+    """points [n,3] fp32, cloud_of int32 [n] (ascending) -> (grid int32 [n,3] from the cloud's own origin, cloud_depth
+    int32 [clouds]).  point_encoder.py:33 / pointtransformer_v3.py:98-101 per cloud."""
+    points, cloud_of = _contig(points, "points"), _contig(cloud_of, "cloud_of", torch.int32)
+    n = points.shape[0]
+    if points.dim() != 2 or points.shape[1] != 3 or cloud_of.shape != (n,):
+        raise AmavError(f"cloud_voxelize: points {tuple(points.shape)} / cloud_of {tuple(cloud_of.shape)}")
+    grid = torch.empty(n, 3, dtype=torch.int32, device=points.device)
+    depth = torch.empty(clouds, dtype=torch.int32, device=points.device)
+    bounds = torch.empty(clouds, 6, dtype=torch.int32, device=points.device)
+    check(_lib.lib().amav_cloud_voxelize(n, int(clouds), points.data_ptr(), cloud_of.data_ptr(), float(resolution),
+                                         grid.data_ptr(), depth.data_ptr(), bounds.data_ptr(), _stream()),
+          "amav_cloud_voxelize")
+    return grid, depth
+
+
+def cloud_codes(grid, cloud_of, cloud_depth):
+    """-> keys int64 [4,n] = cloud << 48 | code for the orders z, z-trans, hilbert, hilbert-trans."""
+    grid, cloud_of = _contig(grid, "grid", torch.int32), _contig(cloud_of, "cloud_of", torch.int32)
+    cloud_depth = _contig(cloud_depth, "cloud_depth", torch.int32)
+    n = grid.shape[0]
+    keys = torch.empty(4, n, dtype=torch.int64, device=grid.device)
+    check(_lib.lib().amav_cloud_codes(n, grid.data_ptr(), cloud_of.data_ptr(), cloud_depth.data_ptr(), keys.data_ptr(),
+                                      _stream()), "amav_cloud_codes")
+    return keys
+
+
+def cloud_neighbors(grid, cloud_of, cloud_depth, cloud_start, sorted_keys, order, ksize):
+    """-> nbr int32 [n, ksize^3]: the rows a submanifold convolution gathers (-1: empty voxel)."""
+    grid, cloud_of = _contig(grid, "grid", torch.int32), _contig(cloud_of, "cloud_of", torch.int32)
+    cloud_depth, cloud_start = _contig(cloud_depth, "cloud_depth", torch.int32), _contig(cloud_start, "cloud_start", torch.int32)
+    sorted_keys, order = _contig(sorted_keys, "sorted_keys", torch.int64), _contig(order, "order", torch.int64)
+    n = grid.shape[0]
+    if sorted_keys.shape != (n,) or order.shape != (n,) or cloud_start.shape[0] != cloud_depth.shape[0] + 1:
+        raise AmavError("cloud_neighbors: sorted_keys / order must be [n], cloud_start [clouds + 1]")
+    nbr = torch.empty(n, ksize ** 3, dtype=torch.int32, device=grid.device)
+    check(_lib.lib().amav_cloud_neighbors(n, int(ksize), grid.data_ptr(), cloud_of.data_ptr(), cloud_depth.data_ptr(),
+                                          cloud_start.data_ptr(), sorted_keys.data_ptr(), order.data_ptr(),
+                                          nbr.data_ptr(), _stream()), "amav_cloud_neighbors")
+    return nbr
+
+
+def subm_gather(products, nbr, bias=None):
+    """products [n, taps, cout] (= feat x all tap weights), nbr int32 [n, taps] -> [n, cout]."""
+    products, nbr = _contig(products, "products"), _contig(nbr, "nbr", torch.int32)
+    n, taps, cout = products.shape
+    if nbr.shape != (n, taps):
+        raise AmavError(f"subm_gather: nbr {tuple(nbr.shape)} does not match products {tuple(products.shape)}")
+    out = torch.empty(n, cout, device=products.device)
+    check(_lib.lib().amav_subm_gather(n, taps, cout, products.data_ptr(), nbr.data_ptr(),
+                                      None if bias is None else _shaped(bias, "bias", (cout,)).data_ptr(), out.data_ptr(),
+                                      _stream()), "amav_subm_gather")
+    return out
+
+
+def patch_attention(qkv, order, patch_desc, heads, max_patch, scale=None):
+    """qkv [n, 3*C] (q | k | v), order int64 [n], patch_desc int32 [patches,4] -> [n, C] (include/amav.h)."""
+    qkv, order = _contig(qkv, "qkv"), _contig(order, "order", torch.int64)
+    patch_desc = _contig(patch_desc, "patch_desc", torch.int32)
+    n, C3 = qkv.shape
+    C = C3 // 3
+    D = C // heads
+    if C3 != 3 * heads * D or order.shape != (n,) or patch_desc.dim() != 2 or patch_desc.shape[1] != 4:
+        raise AmavError("patch_attention: shapes do not match")
+    out = torch.empty(n, C, device=qkv.device)
+    check(_lib.lib().amav_patch_attention(patch_desc.shape[0], int(max_patch), int(heads), D, qkv.data_ptr(),
+                                          order.data_ptr(), patch_desc.data_ptr(), out.data_ptr(),
+                                          float(scale if scale is not None else D ** -0.5), _stream()),
+          "amav_patch_attention")
+    return out
+
+
+def cluster_max(x, members, seg, scale, shift):
+    """x [n,C], members int64 [n] (rows grouped by cluster), seg int64 [clusters+1] -> gelu(max * scale + shift) [clusters,C]."""
+    x, members, seg = _contig(x, "x"), _contig(members, "members", torch.int64), _contig(seg, "seg", torch.int64)
+    C = x.shape[1]
+    clusters = seg.shape[0] - 1
+    out = torch.empty(clusters, C, device=x.device)
+    check(_lib.lib().amav_cluster_max(clusters, C, x.data_ptr(), members.data_ptr(), seg.data_ptr(),
+                                      _shaped(scale, "scale", (C,)).data_ptr(), _shaped(shift, "shift", (C,)).data_ptr(),
+                                      out.data_ptr(), _stream()), "amav_cluster_max")
+    return out
+
+
+def bn_gelu(x, scale, shift):
+    """gelu(x * scale + shift) for x [rows, C] (BatchNorm in eval mode folded to scale / shift)."""
+    x = _contig(x, "x")
+    rows, C = x.shape
+    out = torch.empty_like(x)
+    check(_lib.lib().amav_bn_gelu(rows, C, x.data_ptr(), _shaped(scale, "scale", (C,)).data_ptr(),
+                                  _shaped(shift, "shift", (C,)).data_ptr(), out.data_ptr(), _stream()), "amav_bn_gelu")
+    return out
+
+
+def unpool_merge(x, scale, shift, up, cluster):
+    """-> (skip = gelu(x * scale + shift), skip + up[cluster]) for x [n,C], up [m,C], cluster int64 [n]."""
+    x, up, cluster = _contig(x, "x"), _contig(up, "up"), _contig(cluster, "cluster", torch.int64)
+    n, C = x.shape
+    if up.shape[1] != C or cluster.shape != (n,):
+        raise AmavError("unpool_merge: shapes do not match")
+    skip, total = torch.empty_like(x), torch.empty_like(x)
+    check(_lib.lib().amav_unpool_merge(n, C, x.data_ptr(), _shaped(scale, "scale", (C,)).data_ptr(),
+                                       _shaped(shift, "shift", (C,)).data_ptr(), up.data_ptr(), cluster.data_ptr(),
+                                       skip.data_ptr(), total.data_ptr(), _stream()), "amav_unpool_merge")
+    return skip, total

@@ -1,0 +1,308 @@
+"""Point refiner: the reference's PTv3Encoder / PointTransformerV3 on MI355X.
+
+Mirrors src/models/point_transformer/point_encoder.py:6-40 and pointtransformer_v3.py:795-991 -- same constructor
+arguments, same module tree, so `point_encoder.point_transformer.*` checkpoint keys load -- with the deterministic
+semantics of DESIGN.md section 4.2 (the reference permutes its serialisation orders with an unseeded randperm, feeds
+negative grid coordinates to its encoders and puts several points into one voxel of spconv's hash: it defines no
+reproducible output):
+
+  * orders keep their configured sequence (z, z-trans, hilbert, hilbert-trans);
+  * every cloud (frame) is processed as the reference processes a batch of ONE: grid origin, serialisation depth and
+    attention patch size are the cloud's own, so frames stay independent (they are the unit of data parallelism);
+  * sorts are stable; a voxel is seen by neighbouring voxels through its lowest-index point.
+
+All clouds of a pass run batched: one key sort per order, one neighbour table per level, one dense GEMM per
+convolution (all taps at once) + a gather kernel, one attention launch per block (patches of all clouds).  The sparse /
+serialised operators are HIP kernels (csrc/cloud.hip); Linear / LayerNorm / sort / prefix sums are torch library calls
+on the same stream.  Inference only.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from ._lib import AmavError
+
+ORDERS = ("z", "z-trans", "hilbert", "hilbert-trans")
+_CODE_MASK = (1 << 48) - 1
+
+
+class SubMConv3d(nn.Module):
+    """Parameter holder with spconv 2.x's SubMConv3d layout: weight [C_out, k, k, k, C_in] (+ bias)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, bias=True):
+        super().__init__()
+        self.in_channels, self.out_channels, self.kernel_size = in_channels, out_channels, kernel_size
+        k = kernel_size
+        self.weight = nn.Parameter(torch.empty(out_channels, k, k, k, in_channels))
+        nn.init.kaiming_uniform_(self.weight.view(out_channels, -1), a=5 ** 0.5)
+        self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
+        self._flat = None
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        w = state_dict.get(prefix + "weight")
+        k = self.kernel_size
+        if w is not None and tuple(w.shape) == (k, k, k, self.in_channels, self.out_channels) != tuple(self.weight.shape):
+            state_dict[prefix + "weight"] = w.permute(4, 0, 1, 2, 3).contiguous()  # spconv 1.x / 2.0 layout
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+    def flat_weight(self):
+        """[taps * C_out, C_in]: all taps as ONE GEMM operand (row = tap * C_out + c_out)."""
+        ver = (self.weight._version, self.weight.data_ptr())
+        if self._flat is None or self._flat[0] != ver:
+            w = self.weight.detach().reshape(self.out_channels, -1, self.in_channels).permute(1, 0, 2)
+            self._flat = (ver, w.reshape(-1, self.in_channels).contiguous())
+        return self._flat[1]
+
+    def forward(self, feat, nbr):
+        taps = self.kernel_size ** 3
+        products = F.linear(feat, self.flat_weight()).view(feat.shape[0], taps, self.out_channels)
+        return ops.subm_gather(products, nbr, None if self.bias is None else self.bias.detach())
+
+
+def _bn_fold(bn):
+    """BatchNorm1d in eval mode as (scale, shift)."""
+    ver = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version, bn.weight.data_ptr())
+    cached = getattr(bn, "_amav_fold", None)
+    if cached is None or cached[0] != ver:
+        scale = bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)
+        cached = (ver, scale.contiguous(), (bn.bias.detach() - bn.running_mean * scale).contiguous())
+        bn._amav_fold = cached
+    return cached[1], cached[2]
+
+
+def _bn(channels):
+    return nn.BatchNorm1d(channels, eps=1e-3, momentum=0.01)  # pointtransformer_v3.py:857
+
+
+class MLP(nn.Module):
+    def __init__(self, channels, hidden):
+        super().__init__()
+        self.fc1, self.fc2 = nn.Linear(channels, hidden), nn.Linear(hidden, channels)
+
+    def forward(self, x):
+        return self.fc2(F.gelu(self.fc1(x)))
+
+
+class SerializedAttention(nn.Module):
+    """pointtransformer_v3.py:328-499 (enable_flash=False: patch = min(points of the cloud, patch_size))."""
+
+    def __init__(self, channels, num_heads, patch_size, order_index):
+        super().__init__()
+        if channels % num_heads or channels // num_heads not in (16, 32, 64):
+            raise AmavError(f"SerializedAttention: head dim {channels}/{num_heads} (16, 32 and 64 are built)")
+        self.channels, self.num_heads, self.patch_size, self.order_index = channels, num_heads, patch_size, order_index
+        self.qkv = nn.Linear(channels, channels * 3)
+        self.proj = nn.Linear(channels, channels)
+
+    def forward(self, feat, level):
+        desc, max_patch = level.patches(self.patch_size)
+        out = ops.patch_attention(self.qkv(feat), level.order[self.order_index], desc, self.num_heads, max_patch)
+        return self.proj(out)
+
+
+class Block(nn.Module):
+    """pointtransformer_v3.py:528-615 (pre-norm; DropPath is the identity at inference)."""
+
+    def __init__(self, channels, num_heads, patch_size, mlp_ratio, order_index):
+        super().__init__()
+        self.cpe = nn.Sequential(SubMConv3d(channels, channels, 3), nn.Linear(channels, channels), nn.LayerNorm(channels))
+        self.norm1 = nn.Sequential(nn.LayerNorm(channels))
+        self.attn = SerializedAttention(channels, num_heads, patch_size, order_index)
+        self.norm2 = nn.Sequential(nn.LayerNorm(channels))
+        self.mlp = nn.Sequential(MLP(channels, int(channels * mlp_ratio)))
+
+    def forward(self, feat, level, conv_in=None):
+        x = self.cpe[0](feat if conv_in is None else conv_in, level.neighbors(3))
+        feat = feat + self.cpe[2](self.cpe[1](x))
+        feat = feat + self.attn(self.norm1(feat), level)
+        return feat + self.mlp(self.norm2(feat))
+
+
+class SerializedPooling(nn.Module):
+    """pointtransformer_v3.py:618-721: stride-2 grid pooling along the z-order (max), BatchNorm, GELU."""
+
+    def __init__(self, in_channels, out_channels, stride):
+        super().__init__()
+        if stride != 2:
+            raise AmavError(f"SerializedPooling: stride {stride} (the reference configures 2 everywhere)")
+        self.proj = nn.Linear(in_channels, out_channels)
+        self.norm = nn.Sequential(_bn(out_channels))
+
+    def forward(self, feat, level):
+        child, cluster, seg = level.pool()
+        scale, shift = _bn_fold(self.norm[0])
+        return ops.cluster_max(self.proj(feat), level.order[0], seg, scale, shift), child, cluster
+
+
+class SerializedUnpooling(nn.Module):
+    """pointtransformer_v3.py:724-759: both branches Linear + BatchNorm + GELU, parent += child[cluster]."""
+
+    def __init__(self, in_channels, skip_channels, out_channels):
+        super().__init__()
+        self.proj = nn.Sequential(nn.Linear(in_channels, out_channels), _bn(out_channels))
+        self.proj_skip = nn.Sequential(nn.Linear(skip_channels, out_channels), _bn(out_channels))
+
+    def forward(self, child_feat, parent_feat, cluster):
+        up = ops.bn_gelu(self.proj[0](child_feat), *_bn_fold(self.proj[1]))
+        # -> (skip branch, sum): the next block's convolution reads the skip branch alone (the reference refreshes the
+        # parent's sparse tensor in proj_skip, :250-255, but not after the sum at :755), its shortcut is the sum
+        return ops.unpool_merge(self.proj_skip[0](parent_feat), *_bn_fold(self.proj_skip[1]), up, cluster)
+
+
+class Level:
+    """Serialisation state of all clouds at one resolution (what the reference keeps in a `Point`)."""
+
+    def __init__(self, grid, cloud_of, depth, counts, keys):
+        self.grid, self.cloud_of, self.depth, self.counts, self.keys = grid, cloud_of, depth, counts, keys
+        self.n = int(grid.shape[0])
+        dev = grid.device
+        starts = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+        self.starts_host = starts
+        self.cloud_start = torch.from_numpy(starts).to(dev)
+        self.sorted_keys, self.order = torch.sort(keys, dim=1, stable=True)  # [4,n] each
+        self._nbr, self._patches = {}, {}
+
+    def neighbors(self, ksize):
+        if ksize not in self._nbr:
+            self._nbr[ksize] = ops.cloud_neighbors(self.grid, self.cloud_of, self.depth, self.cloud_start,
+                                                   self.sorted_keys[0], self.order[0], ksize)
+        return self._nbr[ksize]
+
+    def patches(self, patch_size):
+        """patch_desc [P,4] int32 (first, K, own, 0) for every patch of every cloud + the largest K."""
+        if patch_size not in self._patches:
+            rows = []
+            for f, c in enumerate(self.counts):
+                if c <= 0:
+                    continue
+                K = min(int(c), patch_size)
+                base = int(self.starts_host[f])
+                rows += [(base + p, K, min(K, int(c) - p), 0) for p in range(0, int(c), K)]
+            desc = torch.from_numpy(np.asarray(rows, dtype=np.int32).reshape(-1, 4)).to(self.grid.device)
+            self._patches[patch_size] = (desc, max(r[1] for r in rows))
+        return self._patches[patch_size]
+
+    def pool(self):
+        """-> (child Level, cluster int64 [n]: child row of every point, seg int64 [m+1] over order[0])."""
+        dev = self.grid.device
+        shift = (self.depth >= 1).to(torch.int64)                 # pointtransformer_v3.py:649-651, per cloud
+        sh3 = (shift * 3)[self.cloud_of.long()]
+        pkeys = (self.keys & ~_CODE_MASK) | ((self.keys & _CODE_MASK) >> sh3)
+        order0 = self.order[0]
+        sp = pkeys[0][order0]
+        first = torch.ones(self.n, dtype=torch.bool, device=dev)
+        first[1:] = sp[1:] != sp[:-1]
+        cid = torch.cumsum(first, 0) - 1
+        seg_head = torch.nonzero(first)[:, 0]
+        m = int(seg_head.shape[0])
+        seg = torch.cat([seg_head, torch.tensor([self.n], device=dev)])
+        head = order0[seg_head]
+        cluster = torch.empty(self.n, dtype=torch.int64, device=dev)
+        cluster[order0] = cid
+        ccloud = self.cloud_of[head]
+        counts = torch.bincount(ccloud.long(), minlength=len(self.counts)).cpu().numpy()
+        cgrid = self.grid[head] >> shift[ccloud.long()].to(torch.int32)[:, None]
+        child = Level(cgrid.contiguous(), ccloud.contiguous(), (self.depth - shift.to(torch.int32)).contiguous(), counts,
+                      pkeys[:, head].contiguous())
+        assert child.n == m
+        return child, cluster, seg
+
+
+class PointTransformerV3(nn.Module):
+    """pointtransformer_v3.py:795-991 (cls_mode=False, no PDNorm, no RPE, no flash): constructor arguments by the
+    reference's names; `drop_path`, `shuffle_orders`, `enable_flash` are accepted and have no effect at inference /
+    are replaced by the deterministic semantics above."""
+
+    def __init__(self, in_channels=6, order=ORDERS, stride=(2, 2, 2, 2), enc_depths=(2, 2, 2, 6, 2),
+                 enc_channels=(32, 64, 128, 256, 512), enc_num_head=(2, 4, 8, 16, 32),
+                 enc_patch_size=(1024, 1024, 1024, 1024, 1024), dec_depths=(2, 2, 2, 2), dec_channels=(64, 64, 128, 256),
+                 dec_num_head=(4, 4, 8, 16), dec_patch_size=(1024, 1024, 1024, 1024), mlp_ratio=4, drop_path=0.3,
+                 shuffle_orders=True, enable_flash=False, grid_resolution=100):
+        super().__init__()
+        if tuple(order) != ORDERS:
+            raise AmavError(f"PointTransformerV3: orders {tuple(order)} (the kernels build {ORDERS})")
+        stages = len(enc_depths)
+        if not (stages == len(stride) + 1 == len(enc_channels) == len(enc_num_head) == len(enc_patch_size)
+                == len(dec_depths) + 1 == len(dec_channels) + 1 == len(dec_num_head) + 1 == len(dec_patch_size) + 1):
+            raise AmavError("PointTransformerV3: stage lists of inconsistent length")  # :835-843
+        self.num_stages, self.grid_resolution = stages, float(grid_resolution)
+        self.enc_depths, self.dec_depths = tuple(enc_depths), tuple(dec_depths)
+        self.embedding = nn.Module()
+        self.embedding.stem = nn.Module()
+        self.embedding.stem.conv = SubMConv3d(in_channels, enc_channels[0], 5, bias=False)  # :776-784 (padding ignored)
+        self.embedding.stem.norm = _bn(enc_channels[0])
+        self.enc = nn.Module()
+        for s in range(stages):
+            enc = nn.Module()
+            if s > 0:
+                enc.down = SerializedPooling(enc_channels[s - 1], enc_channels[s], stride[s - 1])
+            for i in range(enc_depths[s]):
+                setattr(enc, f"block{i}", Block(enc_channels[s], enc_num_head[s], enc_patch_size[s], mlp_ratio,
+                                                i % len(ORDERS)))
+            setattr(self.enc, f"enc{s}", enc)
+        self.dec = nn.Module()
+        dec_channels = list(dec_channels) + [enc_channels[-1]]
+        for s in reversed(range(stages - 1)):
+            dec = nn.Module()
+            dec.up = SerializedUnpooling(dec_channels[s + 1], enc_channels[s], dec_channels[s])
+            for i in range(dec_depths[s]):
+                setattr(dec, f"block{i}", Block(dec_channels[s], dec_num_head[s], dec_patch_size[s], mlp_ratio,
+                                                i % len(ORDERS)))
+            setattr(self.dec, f"dec{s}", dec)
+        self.out_channels = dec_channels[0]
+
+    @torch.no_grad()
+    def forward(self, points, feat):
+        """points [F,N,3], feat [F,N,C_in] (fp32, HIP device) -> [F*N, dec_channels[0]] in the input's point order."""
+        if torch.is_grad_enabled():  # pragma: no cover (no_grad above)
+            raise NotImplementedError
+        Fc, N, _ = points.shape
+        n = Fc * N
+        dev = points.device
+        cloud_of = torch.arange(Fc, device=dev, dtype=torch.int32).repeat_interleave(N)
+        grid, depth = ops.cloud_voxelize(points.reshape(n, 3), cloud_of, Fc, self.grid_resolution)
+        level = Level(grid, cloud_of, depth, np.full(Fc, N, dtype=np.int64), ops.cloud_codes(grid, cloud_of, depth))
+        stem = self.embedding.stem
+        x = ops.bn_gelu(stem.conv(feat.reshape(n, -1).float().contiguous(), level.neighbors(5)), *_bn_fold(stem.norm))
+        stack = []
+        for s in range(self.num_stages):
+            enc = getattr(self.enc, f"enc{s}")
+            if s > 0:
+                x_child, child, cluster = enc.down(x, level)
+                stack.append((level, x, cluster))
+                level, x = child, x_child
+            for i in range(self.enc_depths[s]):
+                x = getattr(enc, f"block{i}")(x, level)
+        for s in reversed(range(self.num_stages - 1)):
+            dec = getattr(self.dec, f"dec{s}")
+            parent, x_parent, cluster = stack.pop()
+            skip, x = dec.up(x, x_parent, cluster)
+            level = parent
+            for i in range(self.dec_depths[s]):
+                x = getattr(dec, f"block{i}")(x, level, conv_in=skip if i == 0 else None)
+        return x
+
+
+class PTv3Encoder(nn.Module):
+    """point_encoder.py:6-40.  cfg: input_dim, stride, enc_channels, enc_depths, dec_channels, dec_depths,
+    enc_num_head, dec_num_head, enc_patch_size, dec_patch_size, enable_flash (reference names); optional
+    `refiner_clouds_per_pass` bounds the working set (clouds are independent, so the split changes nothing)."""
+
+    def __init__(self, cfg=None):
+        super().__init__()
+        self.point_transformer = PointTransformerV3(
+            in_channels=cfg.input_dim, stride=cfg.stride, enc_channels=cfg.enc_channels, enc_depths=cfg.enc_depths,
+            dec_channels=cfg.dec_channels, dec_depths=cfg.dec_depths, enc_num_head=cfg.enc_num_head,
+            dec_num_head=cfg.dec_num_head, enc_patch_size=cfg.enc_patch_size, dec_patch_size=cfg.dec_patch_size,
+            enable_flash=getattr(cfg, "enable_flash", False))
+        self.grid_resolution = 100
+        self.clouds_per_pass = int(getattr(cfg, "refiner_clouds_per_pass", 8))
+
+    def forward(self, pts, feats):
+        """pts [B,N,3], feats [B,N,C] -> [B*N, dec_channels[0]]."""
+        B = pts.shape[0]
+        outs = [self.point_transformer(pts[s:s + self.clouds_per_pass], feats[s:s + self.clouds_per_pass])
+                for s in range(0, B, self.clouds_per_pass)]
+        return outs[0] if len(outs) == 1 else torch.cat(outs)

@@ -281,6 +281,54 @@ int amav_add_layernorm(int64_t rows, int dim, int64_t rows_per_batch, const floa
                        const float *hidden_dev, float *hidden_out_dev, const float *weight_dev, const float *bias_dev,
                        float eps, float *out_norm_dev, void *stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Point refiner: the sparse / serialised operators of the reference's
+ * PointTransformerV3 (src/models/point_transformer/pointtransformer_v3.py:81-145,328-499,618-759; point_encoder.py:25-40;
+ * called from src/models/renderer.py:143-151) over a batch of CLOUDS (one per frame; n = all their points, a
+ * cloud's points contiguous).  Replaces spconv.SubMConv3d (hash-table submanifold convolution), torch_scatter.segment_csr
+ * and the padded-patch softmax attention.  Deterministic semantics (oracle/ptv3.py header): per-cloud
+ * grid origin / depth / patch size, stable sorts, a voxel is seen by its neighbours through its lowest row.
+ *
+ * amav_cloud_voxelize   grid [n,3] = floor(resolution * p) - per-cloud minimum; cloud_depth [clouds] = bit length of
+ *                       the cloud's largest grid coordinate; bounds [clouds,6] int32 scratch.     (point_encoder.py:33)
+ * amav_cloud_codes      keys [4,n] int64 = cloud << 48 | code for the orders z, z-trans, hilbert, hilbert-trans
+ *                       (serialization/default.py:10-27, z_order.py:86-118, hilbert.py:93-190); a stable sort of a row
+ *                       orders every cloud at once.
+ * amav_cloud_neighbors  nbr [n, ksize^3] int32: row gathered by tap (a,b,c) (offset (a,b,c) - ksize/2 on x,y,z), -1
+ *                       where the voxel is empty; centre tap = the row itself.  sorted_keys / order: the z-order keys
+ *                       ascending and the rows in that order; cloud_start [clouds+1] int32.         (spconv SubMConv3d)
+ * amav_subm_gather      out [n,cout] = bias + sum over taps (ascending) of products[nbr[i][tap]][tap][:] with
+ *                       products [n, taps, cout] = feat x W (all taps in one dense GEMM); bias may be NULL.
+ * amav_patch_attention  out [n, heads*head_dim] = softmax(q k^T * scale) v inside patches of a serialised order.
+ *                       qkv [n, 3*heads*head_dim] (q | k | v, head-major inside each); order [n] int64 rows in serialised
+ *                       order; patch_desc [patches,4] int32 = {first sorted position, K, own, 0}: slot j of the patch is
+ *                       sorted position first + j for j < own and first + j - K otherwise (a cloud's last patch borrows
+ *                       the tail of the one before, pointtransformer_v3.py:419-432); only slots < own are stored.
+ *                       head_dim in {16, 32, 64}; max_patch = largest K.                (pointtransformer_v3.py:449-499)
+ * amav_cluster_max      out [clusters,C] = gelu(scale * max over rows members[seg[j]..seg[j+1]) of x + shift)
+ *                       (segment_csr 'max' + BatchNorm(eval) + GELU, pointtransformer_v3.py:693-719)
+ * amav_bn_gelu          out = gelu(x * scale + shift), [rows, C]                                    (:785-788,738-744)
+ * amav_unpool_merge     skip = gelu(x * scale + shift); sum = skip + up[cluster[row]]               (:748-755)
+ */
+int amav_cloud_voxelize(int64_t n, int clouds, const float *points_dev, const int32_t *cloud_of_dev, float resolution,
+                        int32_t *grid_dev, int32_t *cloud_depth_dev, int32_t *bounds_dev, void *stream);
+int amav_cloud_codes(int64_t n, const int32_t *grid_dev, const int32_t *cloud_of_dev, const int32_t *cloud_depth_dev,
+                     int64_t *keys_dev, void *stream);
+int amav_cloud_neighbors(int64_t n, int ksize, const int32_t *grid_dev, const int32_t *cloud_of_dev,
+                         const int32_t *cloud_depth_dev, const int32_t *cloud_start_dev, const int64_t *sorted_keys_dev,
+                         const int64_t *order_dev, int32_t *nbr_dev, void *stream);
+int amav_subm_gather(int64_t n, int taps, int cout, const float *products_dev, const int32_t *nbr_dev,
+                     const float *bias_dev, float *out_dev, void *stream);
+int amav_patch_attention(int patches, int max_patch, int heads, int head_dim, const float *qkv_dev,
+                         const int64_t *order_dev, const int32_t *patch_desc_dev, float *out_dev, float scale,
+                         void *stream);
+int amav_cluster_max(int64_t clusters, int channels, const float *x_dev, const int64_t *members_dev,
+                     const int64_t *seg_dev, const float *scale_dev, const float *shift_dev, float *out_dev, void *stream);
+int amav_bn_gelu(int64_t rows, int channels, const float *x_dev, const float *scale_dev, const float *shift_dev,
+                 float *out_dev, void *stream);
+int amav_unpool_merge(int64_t rows, int channels, const float *x_dev, const float *scale_dev, const float *shift_dev,
+                      const float *up_dev, const int64_t *cluster_dev, float *skip_dev, float *sum_dev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -42,6 +42,14 @@ Two tiers of fixtures (the tier is stored in every file and in the manifest):
                         init_smplx_model / init_smplx_subdivider (absent smplx / pytorch3d) with ToyBody below, with
                         torch_scatter's scatter_max / scatter_mean := oracle/triplane_net.py restatements
 
+            ptv3_codes  (tier 1) serialization.encode for the z / z-trans / hilbert / hilbert-trans orders
+                        (src/models/point_transformer/serialization/default.py:10-27, z_order.py, hilbert.py)
+            ptv3        (tier 2) PointTransformerV3.__init__/forward, Point.serialization, SerializedAttention, Block,
+                        SerializedPooling / Unpooling, Embedding (pointtransformer_v3.py:48-991) one cloud at a time, with
+                        addict.Dict, torch_scatter.segment_csr and spconv's SubMConv3d / SparseConvTensor injected as REAL
+                        modules before the import (`class Point(Dict)` binds its base at import) and torch.randperm /
+                        torch.argsort pinned to the deterministic semantics of oracle/ptv3.py's header
+
 Parameters are not stored: after a reference module is built, every entry of its state_dict is overwritten by
 `seeded_tensor(name, shape)` below, a pure function of the parameter's NAME; the tests rebuild the same values for
 the product modules (which must therefore expose the same names and shapes -- SURVEY Appendix B).
@@ -527,10 +535,152 @@ def fixture_stage1(tn, tok, imf, tr, sd_mod):
     return [t1, t2]
 
 
+# ------------------------------------------------------------------------------------------------ PTv3 refiner
+class AttrDict(dict):
+    """Injected for addict.Dict (absent): a dict whose items are attributes (what Point relies on)."""
+
+    def __getattr__(self, name):
+        try:
+            return self[name]
+        except KeyError:
+            raise AttributeError(name) from None
+
+    def __setattr__(self, name, value):
+        self[name] = value
+
+
+def inject_ptv3_dependencies():
+    """Real (non-placeholder) stand-ins registered BEFORE src.models.point_transformer is imported, because
+    `class Point(Dict)` binds its base at import: addict.Dict := AttrDict, torch_scatter.segment_csr := sorted segment
+    reduce, spconv.pytorch := SubMConv3d / SparseConvTensor on oracle/ptv3.py's restatement (PARITY UNPINNED)."""
+    sys.path.insert(0, ROOT)
+    from oracle import ptv3 as o_pt
+
+    addict = types.ModuleType("addict")
+    addict.Dict = AttrDict
+    sys.modules["addict"] = addict
+
+    def segment_csr(src, indptr, reduce="sum"):
+        rows = []
+        for a, b in zip(indptr[:-1].tolist(), indptr[1:].tolist()):
+            seg = src[a:b]
+            rows.append({"max": lambda t: t.max(0)[0], "mean": lambda t: t.mean(0), "sum": lambda t: t.sum(0),
+                         "min": lambda t: t.min(0)[0]}[reduce](seg))
+        return torch.stack(rows)
+
+    ts = types.ModuleType("torch_scatter")
+    ts.segment_csr = segment_csr
+
+    def inert(name):
+        def fn(*a, **k):
+            RUN_EVENTS.append(("torch_scatter." + name, "call"))
+            raise PlaceholderUsed(f"torch_scatter.{name} is not injected")
+        return fn
+
+    ts.scatter_mean, ts.scatter_max = inert("scatter_mean"), inert("scatter_max")  # triplane_net.py:3 names them
+    sys.modules["torch_scatter"] = ts
+
+    class SparseConvTensor:
+        def __init__(self, features, indices, spatial_shape, batch_size):
+            self.features, self.indices, self.spatial_shape, self.batch_size = features, indices, spatial_shape, batch_size
+            self._tables = {}
+
+        def replace_feature(self, feature):
+            out = SparseConvTensor(feature, self.indices, self.spatial_shape, self.batch_size)
+            out._tables = self._tables
+            return out
+
+    class SubMConv3d(torch.nn.Module):
+        def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True, indice_key=None):
+            super().__init__()
+            self.kernel_size = kernel_size
+            self.weight = torch.nn.Parameter(torch.zeros(out_channels, kernel_size, kernel_size, kernel_size, in_channels))
+            self.bias = torch.nn.Parameter(torch.zeros(out_channels)) if bias else None
+
+        def forward(self, x):
+            if self.kernel_size not in x._tables:
+                x._tables[self.kernel_size] = o_pt.neighbor_table(x.indices[:, 1:].long(), x.indices[:, 0].long(),
+                                                                   self.kernel_size)
+            return x.replace_feature(o_pt.subm_conv3d(x.features, x._tables[self.kernel_size], self.weight, self.bias))
+
+    sp = types.ModuleType("spconv")
+    sp.__path__ = []
+    spt = types.ModuleType("spconv.pytorch")
+    spt.SubMConv3d, spt.SparseConvTensor = SubMConv3d, SparseConvTensor
+    spt.modules = types.SimpleNamespace(is_spconv_module=lambda m: isinstance(m, SubMConv3d))
+    sp.pytorch = spt
+    sys.modules["spconv"], sys.modules["spconv.pytorch"] = sp, spt
+    return ["addict.Dict := AttrDict", "torch_scatter.segment_csr := per-segment torch reduce",
+            "spconv.pytorch.SubMConv3d / SparseConvTensor := oracle/ptv3.py subm_conv3d + neighbor_table (parity unpinned)"]
+
+
+def ptv3_cfg():
+    return dict(in_channels=12, stride=(2, 2), enc_depths=(2, 4, 2), enc_channels=(32, 64, 128), enc_num_head=(2, 4, 4),
+                enc_patch_size=(128, 128, 128), dec_depths=(2, 2), dec_channels=(64, 64), dec_num_head=(1, 2),
+                dec_patch_size=(128, 128))
+
+
+def ptv3_cloud_points(seed, n, extent):
+    """A closed surface (so the 1 cm voxels look like the body's: a shell, a few points per voxel in places)."""
+    g = torch.Generator().manual_seed(seed)
+    d = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1)
+    pts = d * torch.tensor(extent) * (1.0 + 0.05 * torch.randn(n, 1, generator=g))
+    pts[n - n // 10:] = pts[: n // 10] + 0.002 * torch.randn(n // 10, 3, generator=g)  # near-duplicates: shared voxels
+    return pts + torch.tensor([0.03, -0.21, 0.4])  # mixed-sign coordinates, as the body has
+
+
+def fixture_ptv3(ser, ptv3, injected):
+    from oracle import ptv3 as o_pt
+
+    # ---- tier 1: the reference's encode() as shipped
+    arrays, g = {}, torch.Generator().manual_seed(81)
+    depths = [1, 3, 7, 8, 9, 12, 16]
+    for depth in depths:
+        grid = torch.randint(0, 1 << depth, (256, 3), generator=g, dtype=torch.int32)
+        batch = torch.randint(0, 4, (256,), generator=g)
+        arrays[f"grid_{depth}"], arrays[f"batch_{depth}"] = grid, batch
+        for o in o_pt.ORDERS:
+            arrays[f"code_{depth}_{o}"] = ser.encode(grid, batch, depth, order=o)
+    t1 = save("ptv3_codes", 1, ["src/models/point_transformer/serialization/default.py:10-27", "z_order.py:86-118",
+                                "hilbert.py:93-190"], arrays, meta=dict(depths=depths, orders=list(o_pt.ORDERS)))
+
+    # ---- tier 2: PointTransformerV3 through its own constructor / forward on one cloud at a time
+    cfg = ptv3_cfg()
+    real_randperm, real_argsort = torch.randperm, torch.argsort
+    torch.randperm = lambda n, *a, **k: torch.arange(n)                       # definition 1: orders keep their sequence
+    torch.argsort = lambda x, *a, **k: real_argsort(x, *a, stable=True, **k)  # definition 4: ties in index order
+    try:
+        net = ptv3.PointTransformerV3(order=o_pt.ORDERS, drop_path=0.0, shuffle_orders=False, enable_flash=False,
+                                      **cfg).eval()
+        shapes = {k: list(v.shape) for k, v in net.state_dict().items()}
+        net.load_state_dict({k: seeded_tensor("point_encoder.point_transformer." + k, v.shape)
+                             for k, v in net.state_dict().items()})
+        out = {}
+        clouds = [(91, 700, (0.30, 0.45, 0.22)), (92, 300, (0.12, 0.30, 0.10)), (93, 90, (0.05, 0.06, 0.04))]
+        with torch.no_grad():
+            for ci, (seed, n, extent) in enumerate(clouds):
+                pts = ptv3_cloud_points(seed, n, extent)
+                feat = rnd(seed + 100, n, cfg["in_channels"])
+                grid = o_pt.frame_grid(pts).int()
+                point = net({"coord": pts, "grid_size": torch.ones(3) / 100.0, "offset": torch.tensor([n]), "feat": feat,
+                             "grid_coord": grid})
+                out[f"pts_{ci}"], out[f"feat_{ci}"], out[f"grid_{ci}"], out[f"out_{ci}"] = pts, feat, grid, point["feat"]
+                out[f"order_{ci}"] = point["serialized_order"]
+    finally:
+        torch.randperm, torch.argsort = real_randperm, real_argsort
+    t2 = save("ptv3", 2, ["src/models/point_transformer/pointtransformer_v3.py:81-145,328-499,528-615,618-759,762-991"],
+              out, meta=dict(cfg={k: list(v) if isinstance(v, tuple) else v for k, v in cfg.items()}, params=shapes,
+                             clouds=len(clouds), injected=injected + [
+                                 "torch.randperm := arange and torch.argsort := stable argsort while the network runs "
+                                 "(the build's deterministic semantics, oracle/ptv3.py header)"]))
+    return [t1, t2]
+
+
 def main():
     if not os.path.isdir(os.path.join(REFERENCE, "src")):
         raise SystemExit(f"{REFERENCE}/src not found: this generator only runs in the build container")
     absent = install_placeholders()
+    injected = inject_ptv3_dependencies()  # before anything imports src.models.point_transformer (renderer.py does)
     sys.path.insert(0, REFERENCE)
     sys.dont_write_bytecode = True  # /root/reference is read-only; leave it untouched
     gu = importlib.import_module("src.utils.graphic_utils")
@@ -542,18 +692,21 @@ def main():
     tn = importlib.import_module("src.models.triplane_net")
     tok = importlib.import_module("src.models.tokenizers")
     imf = importlib.import_module("src.models.image_feature")
-    for m in (gu, mu, tr, tan, sd_mod, rd, tn, tok, imf):
+    ser = importlib.import_module("src.models.point_transformer.serialization")
+    ptv3 = importlib.import_module("src.models.point_transformer.pointtransformer_v3")
+    for m in (gu, mu, tr, tan, sd_mod, rd, tn, tok, imf, ser, ptv3):
         assert os.path.realpath(m.__file__).startswith(os.path.realpath(REFERENCE)), m.__file__
     PHASE["name"] = "run"
     torch.manual_seed(0)
     torch.set_num_threads(1)  # bit-reproducible sums
     entries = [fixture_camera(gu), fixture_reducers(tan), fixture_feedforward(tr), fixture_triplane(rd, mu),
-               fixture_audio_net(tan, tr), fixture_smplx_decoder(sd_mod)] + fixture_stage1(tn, tok, imf, tr, sd_mod)
+               fixture_audio_net(tan, tr), fixture_smplx_decoder(sd_mod)] + fixture_stage1(tn, tok, imf, tr, sd_mod) + fixture_ptv3(ser, ptv3, injected)
     assert not RUN_EVENTS, f"a placeholder was used while producing fixtures: {RUN_EVENTS}"
     manifest = {"generator": "tests/golden/make_reference_golden.py", "reference": REFERENCE, "torch": torch.__version__,
                 "absent_packages_mapped_to_inert_placeholders": absent,
                 "placeholder_events_during_import": sorted(set(f"{a}: {b}" for a, b in IMPORT_EVENTS)),
-                "placeholder_uses_during_run": len(RUN_EVENTS), "fixtures": entries}
+                "placeholder_uses_during_run": len(RUN_EVENTS), "fixtures": entries,
+                "injected_before_import": injected}
     with open(os.path.join(HERE, "ref_manifest.json"), "w") as fh:
         json.dump(manifest, fh, indent=1, sort_keys=True)
     for e in entries:

@@ -1,0 +1,157 @@
+"""Point refiner (PTv3) on the GPU against oracle/ptv3.py and the reference-run fixtures ref_ptv3_codes / ref_ptv3.
+
+Integer work (grid, keys, orders, neighbour tables, clusters) is compared bit for bit; floating point within the
+tolerance written at each assert (fp32 sums evaluated in a different order than the CPU's)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import ref_fixture, seeded_params
+
+pytestmark = pytest.mark.gpu
+
+
+def _mods():
+    from audio_motion_avatar_amd import ops, point_transformer
+
+    return ops, point_transformer
+
+
+def _clouds(seed, F, N, extent=(0.3, 0.5, 0.2)):
+    g = torch.Generator().manual_seed(seed)
+    d = torch.nn.functional.normalize(torch.randn(F, N, 3, generator=g), dim=-1)
+    pts = d * torch.tensor(extent) * (1.0 + 0.05 * torch.randn(F, N, 1, generator=g))
+    pts[:, N - N // 8:] = pts[:, : N // 8] + 0.002 * torch.randn(F, N // 8, 3, generator=g)  # shared voxels
+    return pts + torch.randn(F, 1, 3, generator=g) * 0.3
+
+
+def test_codes_bit_exact_against_reference_encode():
+    """amav_cloud_codes == the reference's own encode() (tier-1 fixture) for all four orders, depths 1..16."""
+    ops, _ = _mods()
+    a, meta, _ = ref_fixture("ptv3_codes")
+    for depth in meta["depths"]:
+        grid = a[f"grid_{depth}"].cuda()
+        n = grid.shape[0]
+        keys = ops.cloud_codes(grid, torch.zeros(n, dtype=torch.int32, device="cuda"),
+                               torch.tensor([depth], dtype=torch.int32, device="cuda")).cpu()
+        for k, order in enumerate(meta["orders"]):
+            want = a[f"code_{depth}_{order}"] & ((1 << (3 * depth)) - 1)  # the fixture carries batch << 3 depth on top
+            assert torch.equal(keys[k], want), (depth, order)
+
+
+def test_voxelize_keys_neighbors_bit_exact():
+    from oracle import ptv3 as o_pt
+
+    ops, _ = _mods()
+    F, N = 3, 700
+    pts = _clouds(5, F, N)
+    cloud_of = torch.arange(F, dtype=torch.int32).repeat_interleave(N)
+    grid, depth = ops.cloud_voxelize(pts.reshape(-1, 3).cuda(), cloud_of.cuda(), F)
+    keys = ops.cloud_codes(grid, cloud_of.cuda(), depth)
+    sorted_keys, order = torch.sort(keys, dim=1, stable=True)
+    starts = (torch.arange(F + 1) * N).to(torch.int32).cuda()
+    for f in range(F):
+        g = o_pt.frame_grid(pts[f])
+        assert torch.equal(grid[f * N:(f + 1) * N].cpu().long(), g)
+        batch = torch.zeros(N, dtype=torch.long)
+        code, o_order, _, d = o_pt.serialization(g, batch)
+        assert int(depth[f]) == d
+        assert torch.equal(keys[:, f * N:(f + 1) * N].cpu() & ((1 << 48) - 1), code)
+        assert torch.equal(order[:, f * N:(f + 1) * N].cpu() - f * N, o_order)
+        for ksize in (3, 5):
+            nbr = ops.cloud_neighbors(grid, cloud_of.cuda(), depth, starts, sorted_keys[0], order[0], ksize).cpu().long()
+            want = o_pt.neighbor_table(g, batch, ksize)
+            got = nbr[f * N:(f + 1) * N]
+            got = torch.where(got >= 0, got - f * N, got)
+            assert torch.equal(got, want), (f, ksize)
+
+
+@pytest.mark.parametrize("cin,cout,ksize", [(12, 32, 5), (64, 64, 3)])
+def test_subm_conv_matches_oracle(cin, cout, ksize):
+    from oracle import ptv3 as o_pt
+
+    ops, pt = _mods()
+    N = 400
+    pts = _clouds(7, 1, N)[0]
+    g = o_pt.frame_grid(pts)
+    batch = torch.zeros(N, dtype=torch.long)
+    nbr = o_pt.neighbor_table(g, batch, ksize)
+    gen = torch.Generator().manual_seed(8)
+    feat = torch.randn(N, cin, generator=gen)
+    conv = pt.SubMConv3d(cin, cout, ksize, bias=True)
+    with torch.no_grad():
+        conv.bias.copy_(torch.randn(cout, generator=gen) * 0.1)
+    want = o_pt.subm_conv3d(feat.double(), nbr, conv.weight.detach().double(), conv.bias.detach().double())
+    got = conv.cuda()(feat.cuda(), nbr.to(torch.int32).cuda()).cpu()
+    assert (got.double() - want).abs().max() <= 1e-5 * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.parametrize("heads,dim,counts,patch", [(4, 64, [1300, 512, 70], 512), (2, 32, [300, 130], 128),
+                                                    (2, 16, [257, 33, 64], 128), (1, 64, [5], 512)])
+def test_patch_attention_matches_oracle(heads, dim, counts, patch):
+    """Padded-patch attention incl. a borrowed tail, clouds smaller than the patch and smaller than an MFMA tile."""
+    from oracle import ptv3 as o_pt
+
+    ops, pt = _mods()
+    C = heads * dim
+    n = sum(counts)
+    gen = torch.Generator().manual_seed(11)
+    qkv = torch.randn(n, 3 * C, generator=gen)
+    order = torch.cat([torch.randperm(c, generator=gen) + s for c, s in zip(counts, np.cumsum([0] + counts[:-1]))])
+    level = pt.Level.__new__(pt.Level)
+    level.counts, level.starts_host = counts, np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    level.grid, level._patches = qkv.cuda(), {}
+    desc, max_patch = level.patches(patch)
+    got = ops.patch_attention(qkv.cuda(), order.cuda(), desc, heads, max_patch).cpu()
+    want = torch.empty(n, C, dtype=torch.float64)
+    start = 0
+    for c in counts:
+        o = order[start:start + c] - start
+        inv = torch.empty_like(o)
+        inv[o] = torch.arange(c)
+        K, pad, unpad = o_pt.patch_layout(c, patch)
+        x = qkv[start:start + c].double()[o[pad]]
+        q, k, v = x.reshape(-1, K, 3, heads, dim).permute(2, 0, 3, 1, 4).unbind(0)
+        att = torch.softmax((q * dim ** -0.5) @ k.transpose(-2, -1), -1)
+        want[start:start + c] = (att @ v).transpose(1, 2).reshape(-1, C)[unpad[inv]]
+        start += c
+    assert (got.double() - want).abs().max() <= 2e-6 * max(1.0, float(want.abs().max()))
+
+
+def _reference_net(meta):
+    _, pt = _mods()
+    cfg = meta["cfg"]
+    net = pt.PointTransformerV3(order=pt.ORDERS, **cfg).eval()
+    assert {k: list(v.shape) for k, v in net.state_dict().items()} == meta["params"]  # names + shapes of the reference
+    net.load_state_dict(seeded_params(meta["params"], "point_encoder.point_transformer."))
+    return net.cuda()
+
+
+def test_network_matches_reference_run():
+    """PointTransformerV3 on the HIP path == the reference's classes run on CPU (tier-2 fixture), cloud by cloud."""
+    a, meta, _ = ref_fixture("ptv3")
+    net = _reference_net(meta)
+    for ci in range(meta["clouds"]):
+        out = net(a[f"pts_{ci}"][None].cuda(), a[f"feat_{ci}"][None].cuda()).cpu()
+        ref = a[f"out_{ci}"]
+        err = float((out - ref).abs().max())
+        assert err <= 1e-4 * max(1.0, float(ref.abs().max())), (ci, err)
+
+
+def test_batched_clouds_equal_single_clouds():
+    """Clouds of one pass do not see each other: a batch of clouds == each cloud alone (definition 2), and vs oracle."""
+    from oracle import ptv3 as o_pt
+
+    a, meta, _ = ref_fixture("ptv3")
+    net = _reference_net(meta)
+    F, N = 3, 420
+    pts = _clouds(21, F, N, extent=(0.2, 0.35, 0.15))
+    feat = torch.randn(F, N, meta["cfg"]["in_channels"], generator=torch.Generator().manual_seed(22))
+    both = net(pts.cuda(), feat.cuda()).cpu().reshape(F, N, -1)
+    for f in range(F):
+        alone = net(pts[f:f + 1].cuda(), feat[f:f + 1].cuda()).cpu()
+        # not bit-equal: the GEMM library may split a [3N, C] and an [N, C] product differently
+        assert (both[f] - alone[0:N]).abs().max() <= 2e-5 * max(1.0, float(alone.abs().max())), f
+    p = {"pe.point_transformer." + k: v for k, v in seeded_params(meta["params"], "point_encoder.point_transformer.").items()}
+    want = o_pt.encoder_forward(p, "pe.", pts, feat, meta["cfg"]).reshape(F, N, -1)
+    assert (both - want).abs().max() <= 1e-4 * max(1.0, float(want.abs().max()))

@@ -29,7 +29,8 @@ def test_manifest_says_no_placeholder_was_used_and_tiers_are_declared():
     assert m["placeholder_uses_during_run"] == 0
     tiers = {e["file"]: e["tier"] for e in m["fixtures"]}
     assert tiers == {"ref_camera.npz": 1, "ref_reducers.npz": 1, "ref_feedforward.npz": 1, "ref_triplane.npz": 1,
-                     "ref_audio_net.npz": 2, "ref_smplx_decoder.npz": 2, "ref_stage1_parts.npz": 1, "ref_stage1.npz": 2}
+                     "ref_audio_net.npz": 2, "ref_smplx_decoder.npz": 2, "ref_stage1_parts.npz": 1, "ref_stage1.npz": 2,
+                     "ref_ptv3_codes.npz": 1, "ref_ptv3.npz": 2}
     for need in ("diffusers", "pytorch3d", "smplx", "omegaconf", "diff_gaussian_rasterization"):
         assert need in m["absent_packages_mapped_to_inert_placeholders"]
     for e in m["fixtures"]:
