@@ -33,7 +33,21 @@ class RendererConfig:
     densify_smplx_verts: bool = True
     subdivide_steps: int = 0          # 0 -> 10 000 sampled vertices (BASELINE), reference default 2 -> 30 000
     predict_smplx_params: bool = True
-    no_point_refiner: bool = True     # reference default false (PTv3): SURVEY 8(f) next-row
+    no_point_refiner: bool = True     # reference default false: PTv3 refiner (point_transformer.py); an untrained
+                                      # refiner's last layer is zero (renderer.py:46-47), i.e. offsets == 0
+    # src/configs/model/ptv3_encoder.yaml:5-20 (input_dim = 3 * triplane_feature_dim when None)
+    input_dim: Optional[int] = None
+    stride: Tuple[int, ...] = (2, 2, 2, 2)
+    enc_channels: Tuple[int, ...] = (32, 64, 128, 256, 512)
+    enc_depths: Tuple[int, ...] = (2, 2, 2, 6, 2)
+    dec_channels: Tuple[int, ...] = (256, 128, 256, 512)
+    dec_depths: Tuple[int, ...] = (2, 2, 2, 2)
+    enc_num_head: Tuple[int, ...] = (2, 4, 8, 16, 32)
+    dec_num_head: Tuple[int, ...] = (4, 4, 8, 16)
+    enc_patch_size: Tuple[int, ...] = (512, 512, 512, 512, 512)
+    dec_patch_size: Tuple[int, ...] = (512, 512, 512, 512)
+    enable_flash: bool = False
+    refiner_clouds_per_pass: int = 8  # frames refined together (bounds the working set; frames are independent)
     use_gaussian_splatting: bool = True
     gaussian_feature_dim: int = 256
     rgb: bool = True

@@ -49,9 +49,9 @@ class AudioDrivenAvatar(nn.Module):
         `triplane_gaussian.renderer.` prefixes, main2.py:127-138).  Uses torch.load(weights_only=True): nothing from
         the file is executed.
 
-        Only keys of modules this build does not have are dropped (`point_encoder.*` / `point_refiner.*`: the PTv3
-        refiner; `smplx_model.*`: buffers that come from the SMPL-X file; `triplane_upsampler.*` only when this Renderer
-        was built without one).  A parameter of a module that EXISTS here and is absent from the checkpoint is an
+        Only keys of modules this Renderer was built without are dropped (`point_encoder.*` / `point_refiner.*` with
+        cfg.no_point_refiner, `triplane_upsampler.*` without cfg.upsample_triplane) plus `smplx_model.*` (buffers that
+        come from the SMPL-X file).  A parameter of a module that EXISTS here and is absent from the checkpoint is an
         error -- it would silently stay at its random initialisation -- unless the checkpoint has no entry at all
         under that module's prefix and `strict` is off (a file saved without the renderer, or without the audio net).
         Returns (missing, unexpected) accumulated over both loads; with `strict` unexpected keys raise too."""
@@ -64,7 +64,9 @@ class AudioDrivenAvatar(nn.Module):
         # the renderer appears under both prefixes (it is one shared module); take whichever is present
         rend = {k[len("triplane_gaussian.renderer."):]: v for k, v in state.items()
                 if k.startswith("triplane_gaussian.renderer.")}
-        drop = ["point_encoder.", "point_refiner.", "smplx_model."]  # 8(f) rows / buffers of the SMPL-X file
+        drop = ["smplx_model."]  # buffers of the SMPL-X file
+        if not hasattr(self.renderer, "point_encoder"):
+            drop += ["point_encoder.", "point_refiner."]
         if not hasattr(self.renderer, "triplane_upsampler"):
             drop.append("triplane_upsampler.")
         drop = tuple(drop)

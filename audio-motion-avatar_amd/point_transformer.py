@@ -292,8 +292,9 @@ class PTv3Encoder(nn.Module):
 
     def __init__(self, cfg=None):
         super().__init__()
+        in_channels = getattr(cfg, "input_dim", None) or 3 * cfg.triplane_feature_dim  # ptv3_encoder.yaml:5
         self.point_transformer = PointTransformerV3(
-            in_channels=cfg.input_dim, stride=cfg.stride, enc_channels=cfg.enc_channels, enc_depths=cfg.enc_depths,
+            in_channels=in_channels, stride=cfg.stride, enc_channels=cfg.enc_channels, enc_depths=cfg.enc_depths,
             dec_channels=cfg.dec_channels, dec_depths=cfg.dec_depths, enc_num_head=cfg.enc_num_head,
             dec_num_head=cfg.dec_num_head, enc_patch_size=cfg.enc_patch_size, dec_patch_size=cfg.dec_patch_size,
             enable_flash=getattr(cfg, "enable_flash", False))

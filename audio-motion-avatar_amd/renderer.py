@@ -12,8 +12,9 @@ Changed on purpose (MI355X-first):
     are views into it;
   * the vertex subset is drawn once (seeded) instead of on every forward (renderer.py:287), and no stage prints or
     synchronises (renderer.py:76-82);
-  * the PTv3 point refiner is a SURVEY.md section 8(f) next-row: requesting it raises; `upsample_triplane=True` runs
-    the TriplaneUpsampler through library convolutions (torch / MIOpen), then the same fused decode.
+  * `no_point_refiner=False` runs the PTv3 point refiner (point_transformer.py, deterministic semantics of DESIGN.md
+    section 4.2) between two triplane samplings, as renderer.py:136-158 does; `upsample_triplane=True` runs the
+    TriplaneUpsampler through library convolutions (torch / MIOpen), then the same fused decode.
 There is no CPU path: every tensor must be on the HIP device.
 """
 import numpy as np
@@ -54,9 +55,6 @@ class Renderer(nn.Module):
     def __init__(self, cfg=None, smpl_decoder=None):
         super().__init__()
         self.cfg = cfg
-        if not getattr(cfg, "no_point_refiner", True):
-            raise NotImplementedError("the PTv3 point refiner (renderer.py:34-47,143-151) is a SURVEY 8(f) next-row; "
-                                      "set no_point_refiner=True (an untrained refiner outputs zero offsets anyway)")
         self.smplx_model = self.init_smplx_model()
         # the reference's table (renderer.py:14-18,25); `num_gaussians` overrides it (BASELINE's 50 000-Gaussian stress
         # config has no entry there)
@@ -67,6 +65,15 @@ class Renderer(nn.Module):
             self.triplane_upsampler = TriplaneUpsampler(cfg)
 
         C = cfg.triplane_feature_dim
+        if not getattr(cfg, "no_point_refiner", True):  # renderer.py:34-47
+            from .point_transformer import PTv3Encoder
+
+            self.point_encoder = PTv3Encoder(cfg=cfg)
+            width = self.point_encoder.point_transformer.out_channels  # 256 in the reference's config
+            self.point_refiner = nn.Sequential(nn.Linear(width, 256), nn.ReLU(), nn.Linear(256, 256), nn.ReLU(),
+                                               nn.Linear(256, 3))
+            nn.init.constant_(self.point_refiner[-1].weight, 0)
+            nn.init.constant_(self.point_refiner[-1].bias, 0)
         self.gaussian_decoder = nn.Module()
         self.gaussian_decoder.xyz_layer = nn.Linear(C * 3 + 3, 3)
         self.gaussian_decoder.rotation_layer = nn.Linear(C * 3 + 3, 4)
@@ -132,6 +139,22 @@ class Renderer(nn.Module):
         out = ops.triplane_sample_features(triplane_features.float(), points.float(), self.cfg.radius)
         return out if batched else out.squeeze(0)
 
+    def refine_points(self, triplane_tokens, points):
+        """renderer.py:136-151: features at the initial points -> PTv3 -> 3-layer MLP -> points + offsets.
+        tokens [F,C,3R^2], points [F,N,3] -> refined points [F,N,3].  Frames are refined in groups of
+        cfg.refiner_clouds_per_pass (they do not interact; the group only bounds the working set)."""
+        F, N, _ = points.shape
+        R = self._plane_resolution(triplane_tokens)
+        planes = triplane_tokens.view(F, triplane_tokens.shape[1], 3, R, R).permute(0, 2, 1, 3, 4)
+        step = max(1, int(getattr(self.cfg, "refiner_clouds_per_pass", 8)))
+        refined = torch.empty_like(points)
+        for s in range(0, F, step):
+            pts = points[s:s + step].contiguous()
+            feats = ops.triplane_sample_features(planes[s:s + step], pts, self.cfg.radius)
+            offsets = self.point_refiner(self.point_encoder.point_transformer(pts, feats))
+            refined[s:s + step] = pts + offsets.view(pts.shape)
+        return refined
+
     def _head_weights(self):
         gd = self.gaussian_decoder
         layers = dict(xyz_layer=gd.xyz_layer, rotation_layer=gd.rotation_layer, scaling_layer=gd.scaling_layer,
@@ -171,7 +194,12 @@ class Renderer(nn.Module):
         side_result = side_work() if side_work is not None else None
         vertices = self._posed_vertices(smpl_params)
         transl = smpl_params["transl"].reshape(F, 3).float()
-        if self.cfg.densify_smplx_verts:
+        if hasattr(self, "point_encoder"):
+            if self.cfg.densify_smplx_verts:
+                vertices = ops.points_gather(vertices, self._gather_idx)
+            points = self.refine_points(triplane_tokens, vertices)
+            packed = ops.triplane_sample_decode(proj, points, transl, self.cfg.radius, w_point, out=out)
+        elif self.cfg.densify_smplx_verts:
             packed = ops.triplane_sample_decode_indexed(proj, vertices, self._gather_idx, transl, self.cfg.radius,
                                                         w_point, out=out)
         else:

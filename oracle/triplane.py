@@ -54,9 +54,20 @@ def construct_gaussians(gaussian_params, points, transl):
                 shs=color)
 
 
-def decode_gaussians(params, triplane_features, points, transl, radius):
-    """renderer.py:136-181 with the point refiner bypassed (offset == 0: an untrained refiner's last layer is
-    zero-initialised, renderer.py:46-47; PTv3 is a SURVEY section 8(f) next-row)."""
+def refine_points(params, triplane_features, points, radius, ptv3_cfg):
+    """renderer.py:136-151: initial features -> PTv3Encoder -> point_refiner MLP -> points + offsets (oracle/ptv3.py)."""
+    from . import ptv3
+
+    feats = sample_from_triplane(triplane_features, points, radius)
+    point_features = ptv3.encoder_forward(params, "point_encoder.", points, feats, ptv3_cfg)
+    return points + ptv3.point_refiner(params, "point_refiner.", point_features).reshape(points.shape)
+
+
+def decode_gaussians(params, triplane_features, points, transl, radius, ptv3_cfg=None):
+    """renderer.py:136-181.  Without `ptv3_cfg` the point refiner is bypassed (offset == 0: an untrained refiner's
+    last layer is zero-initialised, renderer.py:46-47)."""
+    if ptv3_cfg is not None:
+        points = refine_points(params, triplane_features, points, radius, ptv3_cfg)
     feats = sample_from_triplane(triplane_features, points, radius)
     decoder_input = torch.cat([points, feats], dim=-1)
     return construct_gaussians(gaussian_heads(params, decoder_input), points, transl)

@@ -134,3 +134,33 @@ def test_smplx_file_with_ten_shape_and_ten_expression_components(tmp_path):
     b = bm._npz_arrays(str(tmp_path / "big.npz"), 10, 10, True)
     assert np.array_equal(b["expr_dirs"], big["shapedirs"][:, :, 300:310])
     assert np.array_equal(b["shapedirs"], big["shapedirs"][:, :, :10])
+
+
+def test_reference_checkpoint_keeps_refiner_keys():
+    """point_encoder.* / point_refiner.* are loaded when the Renderer has the refiner (spconv's older
+    [k,k,k,C_in,C_out] kernel layout is accepted too) and dropped when it has not."""
+    from audio_motion_avatar_amd.harness import AudioDrivenAvatar
+
+    ptv3 = dict(stride=(2,), enc_depths=(1, 1), enc_channels=(32, 64), enc_num_head=(2, 4), enc_patch_size=(64, 64),
+                dec_depths=(1,), dec_channels=(32,), dec_num_head=(2,), dec_patch_size=(64,))
+    torch.manual_seed(1)
+    src = AudioDrivenAvatar(_small_model_cfg(no_point_refiner=False, **ptv3))
+    with torch.no_grad():
+        for p in src.parameters():
+            p.add_(torch.randn_like(p) * 0.1)
+    state = {"triplane_gaussian.renderer." + k: v.clone() for k, v in src.renderer.state_dict().items()}
+    key = "triplane_gaussian.renderer.point_encoder.point_transformer.embedding.stem.conv.weight"
+    want = state[key].clone()
+    assert want.shape == (32, 5, 5, 5, 96)
+    state[key] = want.permute(1, 2, 3, 4, 0).contiguous()  # spconv 1.x / 2.0 layout
+    dst = AudioDrivenAvatar(_small_model_cfg(no_point_refiner=False, **ptv3))
+    res = dst.load_reference_checkpoint({"state_dict": state})
+    assert not res.missing_keys and not res.unexpected_keys
+    got = dst.renderer.state_dict()
+    assert torch.equal(got["point_encoder.point_transformer.embedding.stem.conv.weight"], want)
+    for k, v in src.renderer.state_dict().items():
+        assert torch.equal(got[k], v), k
+    assert any(k.startswith("point_refiner.") for k in got) and any(".dec.dec0.up.proj_skip.1.running_var" in k for k in got)
+    bare = AudioDrivenAvatar(_small_model_cfg())
+    res = bare.load_reference_checkpoint({"state_dict": state})  # refiner keys dropped, nothing missing
+    assert not res.missing_keys and not res.unexpected_keys

@@ -155,3 +155,48 @@ def test_batched_clouds_equal_single_clouds():
     p = {"pe.point_transformer." + k: v for k, v in seeded_params(meta["params"], "point_encoder.point_transformer.").items()}
     want = o_pt.encoder_forward(p, "pe.", pts, feat, meta["cfg"]).reshape(F, N, -1)
     assert (both - want).abs().max() <= 1e-4 * max(1.0, float(want.abs().max()))
+
+
+def test_renderer_with_point_refiner_matches_oracle():
+    """cfg.no_point_refiner=False: LBS -> sample -> PTv3 -> MLP -> refined points -> fused decode (renderer.py:127-181)
+    against the CPU chain, with a non-zero last refiner layer (the reference zero-initialises it)."""
+    from audio_motion_avatar_amd.config import RendererConfig
+    from audio_motion_avatar_amd.renderer import Renderer
+    from audio_motion_avatar_amd.synthetic import init_random_heads, make_render_inputs
+    from oracle import lbs as o_lbs, subdivide as o_sub, triplane as o_tri
+
+    torch.manual_seed(0)
+    pcfg = dict(stride=(2, 2), enc_depths=(1, 1, 1), enc_channels=(32, 64, 128), enc_num_head=(2, 4, 4),
+                enc_patch_size=(256, 256, 256), dec_depths=(1, 1), dec_channels=(64, 64), dec_num_head=(1, 2),
+                dec_patch_size=(256, 256))
+    cfg = RendererConfig(image_size=(64, 64), subdivide_steps=0, triplane_feature_dim=16, triplane_resolution=8,
+                         predict_smplx_params=False, no_point_refiner=False, num_gaussians=1500, refiner_clouds_per_pass=2,
+                         **pcfg)
+    r = init_random_heads(Renderer(cfg).eval(), std=0.05)
+    assert float(r.point_refiner[-1].weight.abs().max()) == 0.0  # renderer.py:46-47
+    with torch.no_grad():
+        r.point_refiner[-1].weight.normal_(0, 0.02)
+        for m in r.point_encoder.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.normal_(0, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+    F_ = 3
+    tokens, smpl, cam = make_render_inputs(F_, cfg, seed=4)
+    with torch.no_grad():
+        images, gaussians = r(tokens, cam, torch.zeros(1, F_, 1, 1, device="cuda"), smpl)
+        plain = Renderer(RendererConfig(**{**cfg.__dict__, "no_point_refiner": True})).eval()
+        plain.gaussian_decoder.load_state_dict(r.gaussian_decoder.state_dict())
+        _, g_plain = plain(tokens, cam, torch.zeros(1, F_, 1, 1, device="cuda"), smpl)
+    params = {k: v.detach().cpu() for k, v in r.state_dict().items()}
+    levels = o_sub.subdivision_levels(r.smplx_model.faces, r.smplx_model.num_verts, 1)
+    sp = {k: v.cpu() for k, v in smpl.items()}
+    pts = o_lbs.get_smpl_vertices(r.smplx_model.oracle_arrays(torch.float32), sp, densify=(levels, r.subset_index))
+    planes = o_tri.tokens_to_planes(tokens.cpu(), cfg.triplane_resolution)
+    g = o_tri.decode_gaussians(params, planes, pts, sp["transl"].reshape(-1, 3), cfg.radius,
+                               ptv3_cfg={k: list(v) for k, v in pcfg.items()})
+    moved = float((gaussians["xyz"] - g_plain["xyz"]).abs().max())
+    assert moved > 1e-3, moved  # the refiner did move the points
+    for k in ("xyz", "scale", "rot", "opacity", "color"):
+        assert (gaussians[k].cpu() - g[k]).abs().max() <= 1e-4, k
+    assert images.shape == (1, F_, 64, 64, 3)
+
