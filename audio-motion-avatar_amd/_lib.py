@@ -102,8 +102,11 @@ SIGNATURES = {
     "amav_cloud_neighbors": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                             ctypes.c_void_p, ctypes.c_void_p]),
-    "amav_subm_gather": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, c_float_p, ctypes.c_void_p,
-                                        c_float_p, c_float_p, ctypes.c_void_p]),
+    "amav_subm_pair_gemm": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                           c_float_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_float_p,
+                                           c_float_p, ctypes.c_void_p]),
+    "amav_subm_pair_sum": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, c_float_p, ctypes.c_void_p,
+                                          c_float_p, c_float_p, ctypes.c_void_p]),
     "amav_patch_attention": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_float_p,
                                             ctypes.c_void_p, ctypes.c_void_p, c_float_p, ctypes.c_float,
                                             ctypes.c_void_p]),

@@ -13,8 +13,8 @@
 //                          neighbour voxel's z-order key in the cloud's sorted key run (no hash table: the sorted run
 //                          is already there, and "first row of the run of equal keys" is a reproducible choice for
 //                          voxels that hold several points)                                     (spconv SubMConv3d)
-//   amav_subm_gather       out[i] = bias + sum over taps of Y[nbr[i][tap]][tap][:] where Y = feat x W_all is ONE dense
-//                          GEMM over all taps (taps summed in tap order: fixed evaluation order)
+//   amav_subm_pair_gemm    the convolution as a gather-GEMM over the (input row, output row) pairs that exist, grouped
+//                          by tap, fp32 MFMA; amav_subm_pair_sum adds each row's products in tap order (no atomics)
 //   amav_patch_attention   softmax(Q K^T / sqrt(d)) V inside patches of <= 512 consecutive points of a serialised
 //                          order, rows gathered through the order; fp32 MFMA, online softmax   (SerializedAttention)
 //   amav_cluster_max       per-cluster channel maximum + BatchNorm(eval) + GELU                 (SerializedPooling)
@@ -170,23 +170,114 @@ __global__ __launch_bounds__(256) void neighbors_kernel(long long n, int ksize, 
     nbr[gid] = found;
 }
 
-// ---- gather-sum of the per-tap products ----------------------------------------------------------------------------------
-// Y [n][taps][cout]; one thread per (row, 4 channels); taps in ascending order
-__global__ __launch_bounds__(256) void subm_gather_kernel(long long n, int taps, int cout4, const float4 *__restrict__ Y,
-                                                          const int *__restrict__ nbr, const float4 *__restrict__ bias,
-                                                          float4 *__restrict__ out) {
+// ---- submanifold convolution as a gather-GEMM over (input row -> output row) pairs ------------------------------------------
+// Pairs are grouped by tap (tap_start [taps + 1]); pair p of tap t multiplies feat[pair_src[p]] [C_in] by
+// Wt[t] [C_in][C_out] into products[p] [C_out].  Only voxels that exist are multiplied (a body surface fills 7 of the
+// 27 taps of a 3x3x3 kernel and 22 of the 125 of the stem), and the per-row sum over taps is a second, ordered pass
+// (pair_sum_kernel): no atomics, fixed evaluation order.
+// One workgroup = 128 pairs of one tap x NT output channels; K swept in chunks of 32 through LDS (A rows gathered,
+// next chunk's global loads in flight under the MFMAs); wave w owns pairs 32 w .. 32 w + 31, NT / 32 accumulators of
+// v_mfma_f32_32x32x2_f32 (exact fp32 products).
+template <int NT>
+__global__ __launch_bounds__(256) void pair_gemm_kernel(const float *__restrict__ feat, const int *__restrict__ pair_src,
+                                                        const int *__restrict__ tap_start,
+                                                        const int *__restrict__ tile_start, int taps,
+                                                        const float *__restrict__ Wt, float *__restrict__ products,
+                                                        int Cin, int Cout) {
+    constexpr int NACC = NT / 32, KC = 32, LDA = KC + 1, LDB = NT + 4;
+    constexpr int BQ = KC * NT / 4 / 256;  // float4s of the B chunk per thread (1, 2 or 4)
+    __shared__ float As[128 * LDA];
+    __shared__ float Bs[KC * LDB];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, hh = lane >> 5;
+    // which tap this tile belongs to: last t with tile_start[t] <= blockIdx.x (uniform -> scalar loop)
+    int lo = 0, hi = taps;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (tile_start[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
+    }
+    const int tap = lo;
+    const int p0 = tap_start[tap] + ((int)blockIdx.x - tile_start[tap]) * 128, p_end = tap_start[tap + 1];
+    const int n0 = blockIdx.y * NT;
+    const float *W = Wt + (size_t)tap * Cin * Cout + n0;
+
+    // A staging: thread -> rows (tid / 8) + 32 i, 4 consecutive k at (tid % 8) * 4
+    const int arow = tid >> 3, ak = (tid & 7) * 4;
+    const float *ap[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ap[i] = feat + (size_t)pair_src[min(p0 + arow + 32 * i, p_end - 1)] * Cin + ak;
+    // B staging: thread -> float4 number tid + 256 i of the [KC][NT] chunk
+    float4 a0, a1, a2, a3, b[BQ];
+#define AMAV_PG_LOAD(k0_)                                                                            \
+    {                                                                                                \
+        a0 = *reinterpret_cast<const float4 *>(ap[0] + (k0_));                                       \
+        a1 = *reinterpret_cast<const float4 *>(ap[1] + (k0_));                                       \
+        a2 = *reinterpret_cast<const float4 *>(ap[2] + (k0_));                                       \
+        a3 = *reinterpret_cast<const float4 *>(ap[3] + (k0_));                                       \
+        _Pragma("unroll") for (int i = 0; i < BQ; ++i) {                                             \
+            const int t_ = tid + 256 * i, kr_ = t_ / (NT / 4), nc_ = (t_ % (NT / 4)) * 4;            \
+            b[i] = *reinterpret_cast<const float4 *>(W + (size_t)((k0_) + kr_) * Cout + nc_);        \
+        }                                                                                            \
+    }
+#define AMAV_PG_STAGE_A(i_, v_)                          \
+    {                                                    \
+        float *d_ = &As[(arow + 32 * (i_)) * LDA + ak];  \
+        d_[0] = v_.x, d_[1] = v_.y, d_[2] = v_.z, d_[3] = v_.w; \
+    }
+    f32x16 acc[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc[a][t] = 0.f;
+
+    AMAV_PG_LOAD(0)
+    for (int k0 = 0; k0 < Cin; k0 += KC) {
+        AMAV_PG_STAGE_A(0, a0) AMAV_PG_STAGE_A(1, a1) AMAV_PG_STAGE_A(2, a2) AMAV_PG_STAGE_A(3, a3)
+#pragma unroll
+        for (int i = 0; i < BQ; ++i) {
+            const int t_ = tid + 256 * i, kr_ = t_ / (NT / 4), nc_ = (t_ % (NT / 4)) * 4;
+            *reinterpret_cast<float4 *>(&Bs[kr_ * LDB + nc_]) = b[i];
+        }
+        __syncthreads();
+        if (k0 + KC < Cin) AMAV_PG_LOAD(k0 + KC)
+        const float *arow_l = &As[(wave * 32 + c) * LDA + hh];
+        const float *brow_l = &Bs[hh * LDB + c];
+#pragma unroll
+        for (int s = 0; s < KC / 2; ++s) {
+            const float av = arow_l[2 * s];
+#pragma unroll
+            for (int a = 0; a < NACC; ++a)
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, brow_l[2 * s * LDB + 32 * a], acc[a], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#undef AMAV_PG_LOAD
+#undef AMAV_PG_STAGE_A
+    // accumulator register t of lane (c, hh): pair 32 wave + (t & 3) + 8 (t >> 2) + 4 hh, channel n0 + 32 a + c
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int p = p0 + wave * 32 + (t & 3) + 8 * (t >> 2) + 4 * hh;
+        if (p < p_end) {
+#pragma unroll
+            for (int a = 0; a < NACC; ++a) products[(size_t)p * Cout + n0 + 32 * a + c] = acc[a][t];
+        }
+    }
+}
+
+// out[i] = bias + sum over taps (ascending) of products[pair_of[i][tap]]; one thread per (row, 4 channels)
+__global__ __launch_bounds__(256) void pair_sum_kernel(long long n, int taps, int cout4, const float4 *__restrict__ products,
+                                                       const int *__restrict__ pair_of, const float4 *__restrict__ bias,
+                                                       float4 *__restrict__ out) {
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= n * cout4) return;
     const long long i = gid / cout4;
     const int c = (int)(gid - i * cout4);
     float4 acc = bias ? bias[c] : make_float4(0.f, 0.f, 0.f, 0.f);
-    const int *nb = nbr + i * taps;
-    const long long row4 = (long long)taps * cout4;
+    const int *po = pair_of + i * taps;
 #pragma unroll 4
     for (int t = 0; t < taps; ++t) {
-        const int j = nb[t];
-        if (j >= 0) {
-            const float4 y = Y[j * row4 + (long long)t * cout4 + c];
+        const int p = po[t];
+        if (p >= 0) {
+            const float4 y = products[(long long)p * cout4 + c];
             acc.x += y.x, acc.y += y.y, acc.z += y.z, acc.w += y.w;
         }
     }
@@ -418,16 +509,37 @@ extern "C" int amav_cloud_neighbors(int64_t n, int ksize, const int32_t *grid, c
     return check_launch("amav_cloud_neighbors");
 }
 
-extern "C" int amav_subm_gather(int64_t n, int taps, int cout, const float *products, const int32_t *nbr,
-                                const float *bias, float *out, void *stream) {
-    AMAV_REQUIRE(n > 0 && taps > 0 && cout > 0 && cout % 4 == 0, "amav_subm_gather: bad sizes n=%lld taps=%d cout=%d",
+extern "C" int amav_subm_pair_gemm(int64_t pairs, int tiles, int taps, int cin, int cout, const float *feat,
+                                   const int32_t *pair_src, const int32_t *tap_start, const int32_t *tile_start,
+                                   const float *weights, float *products, void *stream_) {
+    AMAV_REQUIRE(pairs > 0 && pairs < INT_MAX && tiles > 0 && taps > 0, "amav_subm_pair_gemm: bad sizes pairs=%lld tiles=%d taps=%d",
+                 (long long)pairs, tiles, taps);
+    AMAV_REQUIRE(cin > 0 && cin % 32 == 0 && cout > 0 && cout % 32 == 0,
+                 "amav_subm_pair_gemm: channels must be multiples of 32 (C_in %d, C_out %d)", cin, cout);
+    AMAV_REQUIRE(feat && pair_src && tap_start && tile_start && weights && products, "amav_subm_pair_gemm: NULL pointer");
+    AMAV_REQUIRE(aligned16(feat) && aligned16(weights) && aligned16(products), "amav_subm_pair_gemm: buffers must be 16-byte aligned");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int nt = cout % 128 == 0 ? 128 : (cout % 64 == 0 ? 64 : 32);
+    const dim3 grid((unsigned)tiles, (unsigned)(cout / nt));
+    if (nt == 128)
+        cloud::pair_gemm_kernel<128><<<grid, 256, 0, stream>>>(feat, pair_src, tap_start, tile_start, taps, weights, products, cin, cout);
+    else if (nt == 64)
+        cloud::pair_gemm_kernel<64><<<grid, 256, 0, stream>>>(feat, pair_src, tap_start, tile_start, taps, weights, products, cin, cout);
+    else
+        cloud::pair_gemm_kernel<32><<<grid, 256, 0, stream>>>(feat, pair_src, tap_start, tile_start, taps, weights, products, cin, cout);
+    return check_launch("amav_subm_pair_gemm");
+}
+
+extern "C" int amav_subm_pair_sum(int64_t n, int taps, int cout, const float *products, const int32_t *pair_of,
+                                  const float *bias, float *out, void *stream) {
+    AMAV_REQUIRE(n > 0 && taps > 0 && cout > 0 && cout % 4 == 0, "amav_subm_pair_sum: bad sizes n=%lld taps=%d cout=%d",
                  (long long)n, taps, cout);
-    AMAV_REQUIRE(products && nbr && out, "amav_subm_gather: NULL pointer");
-    AMAV_REQUIRE(aligned16(products) && aligned16(out) && (!bias || aligned16(bias)), "amav_subm_gather: buffers must be 16-byte aligned");
-    cloud::subm_gather_kernel<<<blocks_for((long long)n * (cout / 4)), 256, 0, static_cast<hipStream_t>(stream)>>>(
-        n, taps, cout / 4, reinterpret_cast<const float4 *>(products), nbr, reinterpret_cast<const float4 *>(bias),
+    AMAV_REQUIRE(products && pair_of && out, "amav_subm_pair_sum: NULL pointer");
+    AMAV_REQUIRE(aligned16(products) && aligned16(out) && (!bias || aligned16(bias)), "amav_subm_pair_sum: buffers must be 16-byte aligned");
+    cloud::pair_sum_kernel<<<blocks_for((long long)n * (cout / 4)), 256, 0, static_cast<hipStream_t>(stream)>>>(
+        n, taps, cout / 4, reinterpret_cast<const float4 *>(products), pair_of, reinterpret_cast<const float4 *>(bias),
         reinterpret_cast<float4 *>(out));
-    return check_launch("amav_subm_gather");
+    return check_launch("amav_subm_pair_sum");
 }
 
 extern "C" int amav_patch_attention(int patches, int max_patch, int heads, int head_dim, const float *qkv,

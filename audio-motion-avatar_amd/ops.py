@@ -635,16 +635,31 @@ def cloud_neighbors(grid, cloud_of, cloud_depth, cloud_start, sorted_keys, order
     return nbr
 
 
-def subm_gather(products, nbr, bias=None):
-    """products [n, taps, cout] (= feat x all tap weights), nbr int32 [n, taps] -> [n, cout]."""
-    products, nbr = _contig(products, "products"), _contig(nbr, "nbr", torch.int32)
-    n, taps, cout = products.shape
-    if nbr.shape != (n, taps):
-        raise AmavError(f"subm_gather: nbr {tuple(nbr.shape)} does not match products {tuple(products.shape)}")
+def subm_pair_gemm(feat, pair_src, tap_start, tile_start, tiles, weights):
+    """feat [n,C_in], pairs grouped by tap (pair_src int32 [P], tap_start / tile_start int32 [taps+1]), weights
+    [taps,C_in,C_out] -> products [P,C_out] (include/amav.h)."""
+    feat, weights = _contig(feat, "feat"), _contig(weights, "weights")
+    pair_src = _contig(pair_src, "pair_src", torch.int32)
+    tap_start, tile_start = _contig(tap_start, "tap_start", torch.int32), _contig(tile_start, "tile_start", torch.int32)
+    taps, cin, cout = weights.shape
+    if feat.shape[1] != cin or tap_start.shape != (taps + 1,) or tile_start.shape != (taps + 1,):
+        raise AmavError("subm_pair_gemm: shapes do not match")
+    products = torch.empty(pair_src.shape[0], cout, device=feat.device)
+    check(_lib.lib().amav_subm_pair_gemm(pair_src.shape[0], int(tiles), taps, cin, cout, feat.data_ptr(),
+                                         pair_src.data_ptr(), tap_start.data_ptr(), tile_start.data_ptr(),
+                                         weights.data_ptr(), products.data_ptr(), _stream()), "amav_subm_pair_gemm")
+    return products
+
+
+def subm_pair_sum(products, pair_of, bias=None):
+    """products [P,C_out], pair_of int32 [n,taps] (-1: no voxel) -> [n,C_out] = bias + sum over taps in tap order."""
+    products, pair_of = _contig(products, "products"), _contig(pair_of, "pair_of", torch.int32)
+    n, taps = pair_of.shape
+    cout = products.shape[1]
     out = torch.empty(n, cout, device=products.device)
-    check(_lib.lib().amav_subm_gather(n, taps, cout, products.data_ptr(), nbr.data_ptr(),
-                                      None if bias is None else _shaped(bias, "bias", (cout,)).data_ptr(), out.data_ptr(),
-                                      _stream()), "amav_subm_gather")
+    check(_lib.lib().amav_subm_pair_sum(n, taps, cout, products.data_ptr(), pair_of.data_ptr(),
+                                        None if bias is None else _shaped(bias, "bias", (cout,)).data_ptr(), out.data_ptr(),
+                                        _stream()), "amav_subm_pair_sum")
     return out
 
 

@@ -11,11 +11,13 @@ reproducible output):
     attention patch size are the cloud's own, so frames stay independent (they are the unit of data parallelism);
   * sorts are stable; a voxel is seen by neighbouring voxels through its lowest-index point.
 
-All clouds of a pass run batched: one key sort per order, one neighbour table per level, one dense GEMM per
-convolution (all taps at once) + a gather kernel, one attention launch per block (patches of all clouds).  The sparse /
+All clouds of a pass run batched: one key sort per order, one neighbour / pair table per level, one gather-GEMM per
+convolution (only the voxel pairs that exist) + an ordered sum, one attention launch per block (patches of all clouds).  The sparse /
 serialised operators are HIP kernels (csrc/cloud.hip); Linear / LayerNorm / sort / prefix sums are torch library calls
 on the same stream.  Inference only.
 """
+from types import SimpleNamespace
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -47,18 +49,23 @@ class SubMConv3d(nn.Module):
             state_dict[prefix + "weight"] = w.permute(4, 0, 1, 2, 3).contiguous()  # spconv 1.x / 2.0 layout
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
-    def flat_weight(self):
-        """[taps * C_out, C_in]: all taps as ONE GEMM operand (row = tap * C_out + c_out)."""
+    def tap_weights(self):
+        """[taps, C_in (padded to a multiple of 32), C_out]: one B operand per tap."""
         ver = (self.weight._version, self.weight.data_ptr())
         if self._flat is None or self._flat[0] != ver:
-            w = self.weight.detach().reshape(self.out_channels, -1, self.in_channels).permute(1, 0, 2)
-            self._flat = (ver, w.reshape(-1, self.in_channels).contiguous())
+            w = self.weight.detach().reshape(self.out_channels, -1, self.in_channels).permute(1, 2, 0)
+            pad = -self.in_channels % 32
+            self._flat = (ver, (F.pad(w, (0, 0, 0, pad)) if pad else w).contiguous())
         return self._flat[1]
 
-    def forward(self, feat, nbr):
-        taps = self.kernel_size ** 3
-        products = F.linear(feat, self.flat_weight()).view(feat.shape[0], taps, self.out_channels)
-        return ops.subm_gather(products, nbr, None if self.bias is None else self.bias.detach())
+    def forward(self, feat, level):
+        """feat [n, C_in] -> [n, C_out]: gather-GEMM over the level's (row, neighbour row) pairs, then the ordered sum."""
+        pairs = level.pairs(self.kernel_size)
+        pad = -self.in_channels % 32
+        if pad:
+            feat = F.pad(feat, (0, pad))
+        products = ops.subm_pair_gemm(feat, pairs.pair_src, pairs.tap_start, pairs.tile_start, pairs.tiles, self.tap_weights())
+        return ops.subm_pair_sum(products, pairs.pair_of, None if self.bias is None else self.bias.detach())
 
 
 def _bn_fold(bn):
@@ -114,7 +121,7 @@ class Block(nn.Module):
         self.mlp = nn.Sequential(MLP(channels, int(channels * mlp_ratio)))
 
     def forward(self, feat, level, conv_in=None):
-        x = self.cpe[0](feat if conv_in is None else conv_in, level.neighbors(3))
+        x = self.cpe[0](feat if conv_in is None else conv_in, level)
         feat = feat + self.cpe[2](self.cpe[1](x))
         feat = feat + self.attn(self.norm1(feat), level)
         return feat + self.mlp(self.norm2(feat))
@@ -162,13 +169,33 @@ class Level:
         self.starts_host = starts
         self.cloud_start = torch.from_numpy(starts).to(dev)
         self.sorted_keys, self.order = torch.sort(keys, dim=1, stable=True)  # [4,n] each
-        self._nbr, self._patches = {}, {}
+        self._nbr, self._patches, self._pairs = {}, {}, {}
 
     def neighbors(self, ksize):
         if ksize not in self._nbr:
             self._nbr[ksize] = ops.cloud_neighbors(self.grid, self.cloud_of, self.depth, self.cloud_start,
                                                    self.sorted_keys[0], self.order[0], ksize)
         return self._nbr[ksize]
+
+    def pairs(self, ksize):
+        """The (neighbour row -> row) pairs of a ksize^3 submanifold convolution, grouped by tap (rows ascending inside
+        a tap): pair_src int32 [P], pair_of int32 [n, taps] (-1: empty voxel), tap_start / tile_start int32 [taps+1]
+        (tiles of 128 pairs, what amav_subm_pair_gemm launches)."""
+        if ksize not in self._pairs:
+            nbr = self.neighbors(ksize)
+            taps, dev = nbr.shape[1], nbr.device
+            hit = nbr.t() >= 0                                   # [taps, n]
+            flat = hit.reshape(-1)
+            idx = torch.cumsum(flat, 0) - 1
+            ends = (idx[self.n - 1::self.n] + 1).cpu().numpy()   # one host sync per (level, kernel size)
+            tap_start = np.concatenate([[0], ends]).astype(np.int32)
+            counts = np.diff(tap_start).astype(np.int64)
+            tile_start = np.concatenate([[0], np.cumsum((counts + 127) // 128)]).astype(np.int32)
+            pair_of = torch.where(flat, idx, -1).view(taps, self.n).t().contiguous().to(torch.int32)
+            self._pairs[ksize] = SimpleNamespace(
+                pair_src=nbr.t()[hit].contiguous(), pair_of=pair_of, tap_start=torch.from_numpy(tap_start).to(dev),
+                tile_start=torch.from_numpy(tile_start).to(dev), tiles=int(tile_start[-1]), count=int(tap_start[-1]))
+        return self._pairs[ksize]
 
     def patches(self, patch_size):
         """patch_desc [P,4] int32 (first, K, own, 0) for every patch of every cloud + the largest K."""
@@ -265,7 +292,7 @@ class PointTransformerV3(nn.Module):
         grid, depth = ops.cloud_voxelize(points.reshape(n, 3), cloud_of, Fc, self.grid_resolution)
         level = Level(grid, cloud_of, depth, np.full(Fc, N, dtype=np.int64), ops.cloud_codes(grid, cloud_of, depth))
         stem = self.embedding.stem
-        x = ops.bn_gelu(stem.conv(feat.reshape(n, -1).float().contiguous(), level.neighbors(5)), *_bn_fold(stem.norm))
+        x = ops.bn_gelu(stem.conv(feat.reshape(n, -1).float().contiguous(), level), *_bn_fold(stem.norm))
         stack = []
         for s in range(self.num_stages):
             enc = getattr(self.enc, f"enc{s}")

@@ -297,8 +297,12 @@ int amav_add_layernorm(int64_t rows, int dim, int64_t rows_per_batch, const floa
  * amav_cloud_neighbors  nbr [n, ksize^3] int32: row gathered by tap (a,b,c) (offset (a,b,c) - ksize/2 on x,y,z), -1
  *                       where the voxel is empty; centre tap = the row itself.  sorted_keys / order: the z-order keys
  *                       ascending and the rows in that order; cloud_start [clouds+1] int32.         (spconv SubMConv3d)
- * amav_subm_gather      out [n,cout] = bias + sum over taps (ascending) of products[nbr[i][tap]][tap][:] with
- *                       products [n, taps, cout] = feat x W (all taps in one dense GEMM); bias may be NULL.
+ * amav_subm_pair_gemm   the convolution's products, only where a voxel exists: pairs grouped by tap (tap_start [taps+1]
+ *                       int32), pair p of tap t: products[p] [cout] = feat[pair_src[p]] [cin] x weights[t] [cin][cout]
+ *                       (weights [taps,cin,cout]); tile_start [taps+1] int32 = prefix sum of ceil(pairs of tap / 128),
+ *                       tiles = its last entry; cin, cout multiples of 32.  fp32 MFMA.
+ * amav_subm_pair_sum    out [n,cout] = bias + sum over taps (ascending) of products[pair_of[i][tap]] (pair_of [n,taps]
+ *                       int32, -1: no voxel); bias may be NULL.
  * amav_patch_attention  out [n, heads*head_dim] = softmax(q k^T * scale) v inside patches of a serialised order.
  *                       qkv [n, 3*heads*head_dim] (q | k | v, head-major inside each); order [n] int64 rows in serialised
  *                       order; patch_desc [patches,4] int32 = {first sorted position, K, own, 0}: slot j of the patch is
@@ -317,8 +321,11 @@ int amav_cloud_codes(int64_t n, const int32_t *grid_dev, const int32_t *cloud_of
 int amav_cloud_neighbors(int64_t n, int ksize, const int32_t *grid_dev, const int32_t *cloud_of_dev,
                          const int32_t *cloud_depth_dev, const int32_t *cloud_start_dev, const int64_t *sorted_keys_dev,
                          const int64_t *order_dev, int32_t *nbr_dev, void *stream);
-int amav_subm_gather(int64_t n, int taps, int cout, const float *products_dev, const int32_t *nbr_dev,
-                     const float *bias_dev, float *out_dev, void *stream);
+int amav_subm_pair_gemm(int64_t pairs, int tiles, int taps, int cin, int cout, const float *feat_dev,
+                        const int32_t *pair_src_dev, const int32_t *tap_start_dev, const int32_t *tile_start_dev,
+                        const float *weights_dev, float *products_dev, void *stream);
+int amav_subm_pair_sum(int64_t n, int taps, int cout, const float *products_dev, const int32_t *pair_of_dev,
+                       const float *bias_dev, float *out_dev, void *stream);
 int amav_patch_attention(int patches, int max_patch, int heads, int head_dim, const float *qkv_dev,
                          const int64_t *order_dev, const int32_t *patch_desc_dev, float *out_dev, float scale,
                          void *stream);

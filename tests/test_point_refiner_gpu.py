@@ -66,24 +66,32 @@ def test_voxelize_keys_neighbors_bit_exact():
             assert torch.equal(got, want), (f, ksize)
 
 
-@pytest.mark.parametrize("cin,cout,ksize", [(12, 32, 5), (64, 64, 3)])
-def test_subm_conv_matches_oracle(cin, cout, ksize):
+@pytest.mark.parametrize("cin,cout,ksize,F,N", [(12, 32, 5, 1, 400), (64, 64, 3, 2, 700), (768, 32, 5, 1, 900),
+                                                 (256, 256, 3, 2, 500), (96, 160, 3, 1, 300)])
+def test_subm_conv_matches_oracle(cin, cout, ksize, F, N):
+    """Gather-GEMM over voxel pairs + ordered sum == the per-tap restatement (fp64), incl. C_in not a multiple of 32,
+    C_out tiles of 32 / 64 / 128 and taps whose pair count is not a multiple of the 128-pair tile."""
     from oracle import ptv3 as o_pt
 
     ops, pt = _mods()
-    N = 400
-    pts = _clouds(7, 1, N)[0]
-    g = o_pt.frame_grid(pts)
-    batch = torch.zeros(N, dtype=torch.long)
-    nbr = o_pt.neighbor_table(g, batch, ksize)
+    pts = _clouds(7, F, N)
+    n = F * N
+    cloud_of = torch.arange(F, dtype=torch.int32).repeat_interleave(N).cuda()
+    grid, depth = ops.cloud_voxelize(pts.reshape(n, 3).cuda(), cloud_of, F)
+    level = pt.Level(grid, cloud_of, depth, np.full(F, N), ops.cloud_codes(grid, cloud_of, depth))
     gen = torch.Generator().manual_seed(8)
-    feat = torch.randn(N, cin, generator=gen)
+    feat = torch.randn(n, cin, generator=gen)
     conv = pt.SubMConv3d(cin, cout, ksize, bias=True)
     with torch.no_grad():
         conv.bias.copy_(torch.randn(cout, generator=gen) * 0.1)
-    want = o_pt.subm_conv3d(feat.double(), nbr, conv.weight.detach().double(), conv.bias.detach().double())
-    got = conv.cuda()(feat.cuda(), nbr.to(torch.int32).cuda()).cpu()
-    assert (got.double() - want).abs().max() <= 1e-5 * max(1.0, float(want.abs().max()))
+    got = conv.cuda()(feat.cuda(), level).cpu()
+    conv = conv.cpu()
+    for f in range(F):
+        nbr = o_pt.neighbor_table(o_pt.frame_grid(pts[f]), torch.zeros(N, dtype=torch.long), ksize)
+        want = o_pt.subm_conv3d(feat[f * N:(f + 1) * N].double(), nbr, conv.weight.detach().double(), conv.bias.detach().double())
+        err = float((got[f * N:(f + 1) * N].double() - want).abs().max())
+        assert err <= 1e-5 * max(1.0, float(want.abs().max())), (f, err)
+    assert level.pairs(ksize).count == int((level.neighbors(ksize) >= 0).sum())
 
 
 @pytest.mark.parametrize("heads,dim,counts,patch", [(4, 64, [1300, 512, 70], 512), (2, 32, [300, 130], 128),
