@@ -20,7 +20,9 @@ same workload), `parity` (GPU vs oracle on that sample; all-pixel maxima and cou
 exits non-zero after printing the line when it is false) and -- default workload at N = 1 only -- `full_path`: a few
 250-frame steps of BASELINE configs[2] (the audio-driven path the >= 30 frames/s/GPU target is quoted on) run after
 the timed region, with their own `roofline` (fp32 MFMA self-attention, HIP events around every launch),
-`cpu_baseline` and `parity` (tokens and frames after two autoregressive steps against the oracle).
+`cpu_baseline` and `parity` (tokens and frames after two autoregressive steps against the oracle), and `point_refiner`:
+the PTv3 point refiner the reference's default renderer runs on the same frames, with the roofline
+of its dominant kernel, the CPU oracle's time for one frame and the parity of the refined points.
 """
 import argparse
 import json
@@ -104,6 +106,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-path", action="store_true",
                     help="default workload only: skip the `full_path` object (a few steps of configs[2] after the timed region)")
+    ap.add_argument("--no-refiner", action="store_true",
+                    help="default workload only: skip the `point_refiner` object (PTv3 refiner, SURVEY 8(f) row 2)")
     ap.add_argument("--full-steps", type=int, default=2, help="steps (250-frame clips) of the `full_path` measurement")
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the workload timed on the CPU oracle")
     ap.add_argument("--chunks", type=int, default=1,
@@ -309,6 +313,83 @@ def oracle_render(renderer, cfg, tokens, smpl_params, cam):
     planes = o_tri.tokens_to_planes(tokens, cfg.triplane_resolution)
     g = o_tri.decode_gaussians(params, planes, pts, smpl_params["transl"].reshape(-1, 3), cfg.radius)
     return o_rast.render_batch(g, cam["intrinsic"], cam["extrinsic"], cfg.image_size, full=True)
+
+
+def measure_point_refiner(args, device, with_cpu, frames=16):
+    """The `point_refiner` object of the default line (the reference's default renderer runs it,
+    renderer.py:143-151): the same synthetic frames with cfg.no_point_refiner=False (ptv3_encoder.yaml), LBS points ->
+    triplane features -> PointTransformerV3 -> offset MLP, timed with HIP events; roofline of its dominant kernel (the
+    stem's 5x5x5 gather-GEMM on fp32 MFMA), CPU oracle on one frame beside it."""
+    import dataclasses
+
+    from audio_motion_avatar_amd import ops
+    from audio_motion_avatar_amd.point_transformer import Level
+    from audio_motion_avatar_amd.renderer import Renderer
+    from audio_motion_avatar_amd.synthetic import init_random_heads, make_render_inputs
+
+    cfg = dataclasses.replace(renderer_config(args, device), no_point_refiner=False)
+    torch.manual_seed(7)
+    r = init_random_heads(Renderer(cfg).eval())
+    with torch.no_grad():
+        r.point_refiner[-1].weight.normal_(0, 0.01)  # the reference zero-initialises it (offsets == 0 until trained)
+        tokens, smpl, _ = make_render_inputs(frames, cfg, seed=42, device=device)
+        verts = ops.points_gather(r._posed_vertices(smpl), r._gather_idx)
+        r.refine_points(tokens[0], verts)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ev[0].record()
+        reps = 3
+        for _ in range(reps):
+            refined = r.refine_points(tokens[0], verts)
+        ev[1].record()
+        torch.cuda.synchronize()
+        ms = ev[0].elapsed_time(ev[1]) / reps
+        # the dominant kernel alone: the stem convolution of one pass (clouds_per_pass frames)
+        per = min(frames, cfg.refiner_clouds_per_pass)
+        pts = verts[:per].contiguous()
+        n = per * pts.shape[1]
+        cloud_of = torch.arange(per, device=device, dtype=torch.int32).repeat_interleave(pts.shape[1])
+        grid, depth = ops.cloud_voxelize(pts.reshape(n, 3), cloud_of, per)
+        import numpy as np
+        level = Level(grid, cloud_of, depth, np.full(per, pts.shape[1]), ops.cloud_codes(grid, cloud_of, depth))
+        stem = r.point_encoder.point_transformer.embedding.stem.conv
+        pairs = level.pairs(5)
+        feat = torch.randn(n, stem.in_channels, device=device)
+        w = stem.tap_weights()
+        for _ in range(2):
+            ops.subm_pair_gemm(feat, pairs.pair_src, pairs.tap_start, pairs.tile_start, pairs.tiles, w)
+        ev[0].record()
+        for _ in range(10):
+            ops.subm_pair_gemm(feat, pairs.pair_src, pairs.tap_start, pairs.tile_start, pairs.tiles, w)
+        ev[1].record()
+        torch.cuda.synchronize()
+        gemm_ms = ev[0].elapsed_time(ev[1]) / 10
+    flops = 2.0 * pairs.count * stem.in_channels * stem.out_channels
+    tf = flops / (gemm_ms * 1e-3) / 1e12
+    N = verts.shape[1]
+    out = {"workload": f"reference ptv3_encoder.yaml (5 stages, 46 M parameters, patch 512) on {N} points per frame, "
+                       f"{frames} frames in passes of {per}; random weights, refiner output layer N(0, 0.01)",
+           "ms_per_frame": ms / frames, "frames_per_s": frames / (ms * 1e-3),
+           "roofline": {"bound": "mfma", "kernel": "pair_gemm_kernel<32> (stem 5x5x5 submanifold convolution, 768 -> 32)",
+                        "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
+                        "avg_launch_ms": gemm_ms, "flops_per_launch": flops, "voxel_pairs": pairs.count,
+                        "taps_hit_of_125": pairs.count / n, "traffic": None}}
+    if with_cpu:
+        from oracle import lbs as o_lbs, subdivide as o_sub, triplane as o_tri
+
+        params = {k: v.detach().cpu() for k, v in r.state_dict().items()}
+        planes = o_tri.tokens_to_planes(tokens[:, :1].cpu(), cfg.triplane_resolution)
+        pcfg = {k: list(getattr(cfg, k)) for k in ("enc_depths", "enc_num_head", "enc_patch_size", "dec_depths",
+                                                   "dec_num_head", "dec_patch_size")}
+        t0 = time.perf_counter()
+        want = o_tri.refine_points(params, planes, verts[:1].cpu(), cfg.radius, pcfg)
+        cpu_s = time.perf_counter() - t0
+        err = float((refined[:1].cpu() - want).abs().max())
+        moved = float((want - verts[:1].cpu()).abs().max())
+        out["cpu_baseline"] = {"value": 1.0 / cpu_s, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": "oracle/ptv3.py + oracle/triplane.py refine_points on frame 0 (torch CPU fp32)"}
+        out["parity"] = {"refined_points_max_abs_diff_m": err, "tol": 1e-5, "largest_offset_m": moved,
+                         "pass": bool(err <= 1e-5)}
+    return out
 
 
 def measure_full_path(args, device, rank, steps, warmup, with_cpu):
@@ -688,12 +769,17 @@ def main():
     if rank == 0 and world == 1 and args.workload == "render" and not args.no_full_path:
         torch.cuda.empty_cache()
         result["full_path"] = measure_full_path(args, device, rank, args.full_steps, 1, not args.no_cpu_baseline)
+    if rank == 0 and world == 1 and args.workload == "render" and not args.no_refiner and N == 10000:
+        torch.cuda.empty_cache()
+        result["point_refiner"] = measure_point_refiner(args, device, not args.no_cpu_baseline)
     if rank == 0:
         emit(result)
     if dist is not None:
         dist.destroy_process_group()
-    if rank == 0 and not result.get("parity", {}).get("pass", True):
-        raise SystemExit("parity check against the CPU oracle FAILED (see the `parity` object of the JSON line)")
+    failed = [k for k in ("parity",) if not result.get(k, {}).get("pass", True)]
+    failed += [k for k in ("full_path", "point_refiner") if not result.get(k, {}).get("parity", {}).get("pass", True)]
+    if rank == 0 and failed:
+        raise SystemExit(f"parity check against the CPU oracle FAILED in {failed} (see the JSON line)")
 
 
 if __name__ == "__main__":

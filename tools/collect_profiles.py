@@ -40,6 +40,9 @@ def counters(pattern):
 
 shutil.copy(one("final_stats/*/*kernel_stats.csv"), os.path.join(out, f"{tag}_bench_render_kernel_stats.csv"))
 shutil.copy(one("final_attn/*/*kernel_stats.csv"), os.path.join(out, f"{tag}_attention_transformer_kernel_stats.csv"))
+ref = one("final_refiner/*/*kernel_stats.csv", required=False)
+if ref:
+    shutil.copy(ref, os.path.join(out, f"{tag}_point_refiner_kernel_stats.csv"))
 src = one("final_bench.json", required=False)
 if src:
     shutil.copy(src, os.path.join(out, f"{tag}_bench_render.json"))
@@ -77,4 +80,6 @@ merged(["final_pmc_sqA/*/*counter_collection.csv", "final_pmc_sqB/*/*counter_col
        keep=("amav::",))
 merged(["final_attn_pmc/*/*counter_collection.csv", "final_attn_pmc2/*/*counter_collection.csv"],
        os.path.join(out, f"{tag}_attention_transformer_pmc_sq.csv"), keep=("amav::", "Cijk", "gemm", "Gemm"))
+merged(["final_refiner_pmc/*/*counter_collection.csv"], os.path.join(out, f"{tag}_point_refiner_pmc_sq.csv"),
+       keep=("amav::", "Cijk"))
 print("wrote", sorted(os.listdir(out)))
