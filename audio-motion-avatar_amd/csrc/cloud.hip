@@ -6,7 +6,7 @@
 // flash_attn; none has a ROCm build.  What replaces them here:
 //
 //   amav_cloud_voxelize    grid = floor(res * p) - per-cloud minimum, serialisation depth per cloud      (point_encoder.py:33,
-//                          pointtransformer_v3.py:98-101; origin / depth per cloud: DESIGN.md section 4.2)
+//                          pointtransformer_v3.py:98-101; origin / depth per cloud: DESIGN.md section 4.5)
 //   amav_cloud_codes       the four serialisation keys (z, z-trans, hilbert, hilbert-trans) of every point, as
 //                          (cloud << 48 | code) so that ONE stable sort orders all clouds    (serialization/*.py)
 //   amav_cloud_neighbors   [n, k^3] table of the rows a submanifold convolution gathers: binary search of the

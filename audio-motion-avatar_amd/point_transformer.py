@@ -2,7 +2,7 @@
 
 Mirrors src/models/point_transformer/point_encoder.py:6-40 and pointtransformer_v3.py:795-991 -- same constructor
 arguments, same module tree, so `point_encoder.point_transformer.*` checkpoint keys load -- with the deterministic
-semantics of DESIGN.md section 4.2 (the reference permutes its serialisation orders with an unseeded randperm, feeds
+semantics of DESIGN.md section 4.5 (the reference permutes its serialisation orders with an unseeded randperm, feeds
 negative grid coordinates to its encoders and puts several points into one voxel of spconv's hash: it defines no
 reproducible output):
 

@@ -13,7 +13,7 @@ Changed on purpose (MI355X-first):
   * the vertex subset is drawn once (seeded) instead of on every forward (renderer.py:287), and no stage prints or
     synchronises (renderer.py:76-82);
   * `no_point_refiner=False` runs the PTv3 point refiner (point_transformer.py, deterministic semantics of DESIGN.md
-    section 4.2) between two triplane samplings, as renderer.py:136-158 does; `upsample_triplane=True` runs the
+    section 4.5) between two triplane samplings, as renderer.py:136-158 does; `upsample_triplane=True` runs the
     TriplaneUpsampler through library convolutions (torch / MIOpen), then the same fused decode.
 There is no CPU path: every tensor must be on the HIP device.
 """

@@ -286,7 +286,7 @@ int amav_add_layernorm(int64_t rows, int dim, int64_t rows_per_batch, const floa
  * PointTransformerV3 (src/models/point_transformer/pointtransformer_v3.py:81-145,328-499,618-759; point_encoder.py:25-40;
  * called from src/models/renderer.py:143-151) over a batch of CLOUDS (one per frame; n = all their points, a
  * cloud's points contiguous).  Replaces spconv.SubMConv3d (hash-table submanifold convolution), torch_scatter.segment_csr
- * and the padded-patch softmax attention.  Deterministic semantics (DESIGN.md section 4.2, oracle/ptv3.py header): per-cloud
+ * and the padded-patch softmax attention.  Deterministic semantics (DESIGN.md section 4.5, oracle/ptv3.py header): per-cloud
  * grid origin / depth / patch size, stable sorts, a voxel is seen by its neighbours through its lowest row.
  *
  * amav_cloud_voxelize   grid [n,3] = floor(resolution * p) - per-cloud minimum; cloud_depth [clouds] = bit length of

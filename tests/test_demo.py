@@ -36,6 +36,30 @@ def test_frame_writer_raw_file_sidecar_and_pipe(tmp_path):
             FrameWriter(str(tmp_path / "clip.mp4"), 8, 12)
 
 
+def test_frame_writer_drives_an_encoder_process(tmp_path):
+    """An .mp4 target starts `ffmpeg` with rawvideo rgb24 on stdin, the clip's audio as second input (main2.py:366-382)
+    and the frames piped in; a stand-in executable records its command line and stdin (ffmpeg is not in this image)."""
+    from audio_motion_avatar_amd.demo import FrameWriter
+
+    fake = tmp_path / "ffmpeg"
+    fake.write_text('#!/bin/sh\nprintf "%s\\n" "$@" > "$(dirname "$0")/args.txt"\ncat > "$(dirname "$0")/stdin.bin"\n')
+    fake.chmod(0o755)
+    frames = torch.randint(0, 256, (3, 4, 6, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(1))
+    with FrameWriter(str(tmp_path / "clip.mp4"), 4, 6, fps=24.0, audio_path="speech.wav", ffmpeg=str(fake)) as w:
+        w.write(frames)
+    args = (tmp_path / "args.txt").read_text().split("\n")
+    assert args[:10] == ["-y", "-f", "rawvideo", "-pix_fmt", "rgb24", "-s", "6x4", "-r", "24.0", "-i"]
+    assert "speech.wav" in args and "aac" in args and "-shortest" in args and args[-2] == str(tmp_path / "clip.mp4")
+    assert np.array_equal(np.fromfile(tmp_path / "stdin.bin", dtype=np.uint8), frames.numpy().ravel())
+    failing = tmp_path / "ffmpeg_bad"
+    failing.write_text("#!/bin/sh\ncat > /dev/null\nexit 3\n")
+    failing.chmod(0o755)
+    w = FrameWriter(str(tmp_path / "bad.mp4"), 4, 6, ffmpeg=str(failing))
+    w.write(frames)
+    with pytest.raises(RuntimeError, match="ffmpeg failed"):
+        w.close()
+
+
 @pytest.mark.gpu
 def test_demo_command_line_renders_a_clip(tmp_path):
     """`python -m audio_motion_avatar_amd.demo`: seeded tokens + a WAV file at 22.05 kHz -> resample -> Wav2Vec2 ->
