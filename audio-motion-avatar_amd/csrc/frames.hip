@@ -267,14 +267,15 @@ __global__ __launch_bounds__(256) void tile_unpack_rows_kernel(int F, int gx, in
 // wire (payload copy) or when it is background now but the buffer does not hold this background yet (clear); every
 // other tile is skipped.  Bytes written per step drop from the dense 786 KB per frame to the stored tiles (+ the few
 // tiles the body moved out of).
-// grid = (frames, buffers); block = 256 threads = 4 waves, wave w walks tile rows w, w + 4, ...; a tile row's
+// grid = (frames, buffers); block = kDeltaWaves waves, wave w walks tile rows w, w + kDeltaWaves, ...; a tile row's
 // selected tiles are written row by row of 16 pixels (48 B = three 16-byte chunks per tile, neighbouring tiles adjoin).
-__global__ __launch_bounds__(256) void tile_unpack_delta_kernel(int F, int gx, int T, int H, int W, int cap,
+constexpr int kDeltaWaves = 16;  // waves per frame: the copies are latency-bound, so many short walkers
+__global__ __launch_bounds__(kDeltaWaves * 64) void tile_unpack_delta_kernel(int F, int gx, int T, int H, int W, int cap,
                                                                 const unsigned char *__restrict__ wire,
                                                                 size_t wire_stride, unsigned char *__restrict__ out,
                                                                 int *__restrict__ state, int *__restrict__ status) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    extern __shared__ int delta_lds[];  // [T] source: slot >= 0, -1 = clear to background, -2 = skip; then 4 x 128 ints of per-wave lists
+    extern __shared__ int delta_lds[];  // [T] source: slot >= 0, -1 = clear to background, -2 = skip; then kDeltaWaves x 128 ints of per-wave lists
     const int f = blockIdx.x, b = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned char *buf = wire + (size_t)b * wire_stride;
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(256) void tile_unpack_delta_kernel(int F, int gx, i
         }
     const int gy = T / gx;
     unsigned char *frame = out + ((size_t)b * F + f) * H * W * 3;
-    for (int ty = wave; ty < gy; ty += 4) {
+    for (int ty = wave; ty < gy; ty += kDeltaWaves) {
         const int rows = min(16, H - ty * 16);
         // the row's tiles that need a write, compacted (gx <= 64: one ballot; wider rows in rounds of 64)
         for (int tx0 = 0; tx0 < gx; tx0 += 64) {
@@ -323,15 +324,25 @@ __global__ __launch_bounds__(256) void tile_unpack_delta_kernel(int F, int gx, i
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            // item k: pixel row r = k / (3 n), entry j = (k % (3 n)) / 3, 16-byte part k % 3 of the tile's 48-byte row
-            const int per_row = 3 * n;
-            for (int k = lane; k < rows * per_row; k += 64) {
-                const int r = k / per_row, rem = k - r * per_row;
-                const int j = rem / 3, part = rem - 3 * j;
-                const int txs = list[2 * j], s2 = list[2 * j + 1];
-                u32x4 v = part == 0 ? bgv[0] : (part == 1 ? bgv[1] : bgv[2]);
-                if (s2 >= 0) v = *reinterpret_cast<const u32x4 *>(payload + (size_t)s2 * kTileBytes + r * 48 + part * 16);
-                *reinterpret_cast<u32x4 *>(frame + ((size_t)(ty * 16 + r) * W + txs * 16) * 3 + part * 16) = v;
+            // item k: pixel row r = k / (3 n), entry j = (k % (3 n)) / 3, 16-byte part k % 3 of the tile's 48-byte row;
+            // four items per lane per round, all loads issued before the first store (the copies are independent)
+            const int per_row = 3 * n, total = rows * per_row;
+            for (int k0 = lane; k0 < total; k0 += 256) {
+                u32x4 v[4];
+                size_t dst[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = min(k0 + 64 * u, total - 1);
+                    const int r = k / per_row, rem = k - r * per_row;
+                    const int j = rem / 3, part = rem - 3 * j;
+                    const int txs = list[2 * j], s2 = list[2 * j + 1];
+                    v[u] = part == 0 ? bgv[0] : (part == 1 ? bgv[1] : bgv[2]);
+                    if (s2 >= 0) v[u] = *reinterpret_cast<const u32x4 *>(payload + (size_t)s2 * kTileBytes + r * 48 + part * 16);
+                    dst[u] = ((size_t)(ty * 16 + r) * W + txs * 16) * 3 + part * 16;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (k0 + 64 * u < total) *reinterpret_cast<u32x4 *>(frame + dst[u]) = v[u];
             }
             __builtin_amdgcn_wave_barrier();  // the list is rewritten by the next round
         }
@@ -428,9 +439,9 @@ extern "C" int amav_frames_unpack_tiles_delta(int num_buffers, int F, int H, int
                  "amav_frames_unpack_tiles_delta: misaligned buffer");
     AMAV_REQUIRE(F <= 65535 * 32768 && num_buffers <= 65535, "amav_frames_unpack_tiles_delta: grid too large");
     const int gx = W / 16, T = gx * ((H + 15) / 16);
-    AMAV_REQUIRE(((size_t)T + 512) * sizeof(int) <= 64 * 1024, "amav_frames_unpack_tiles_delta: %d tiles per frame exceed the LDS table", T);
+    AMAV_REQUIRE(((size_t)T + kDeltaWaves * 128) * sizeof(int) <= 64 * 1024, "amav_frames_unpack_tiles_delta: %d tiles per frame exceed the LDS table", T);
     const dim3 grid((unsigned)F, (unsigned)num_buffers);
-    tile_unpack_delta_kernel<<<grid, 256, ((size_t)T + 4 * 128) * sizeof(int), static_cast<hipStream_t>(stream_)>>>(
+    tile_unpack_delta_kernel<<<grid, kDeltaWaves * 64, ((size_t)T + kDeltaWaves * 128) * sizeof(int), static_cast<hipStream_t>(stream_)>>>(
         F, gx, T, H, W, (int)cap_tiles, static_cast<const unsigned char *>(wire_all), wire_stride, out_rgb8, tile_state,
         status);
     return check_launch("amav_frames_unpack_tiles_delta");

@@ -88,9 +88,13 @@ class FrameAllGather:
     the rasterizer's instance capacity.  wire="dense": plain uint8 RGB frames (ops.frames_to_rgb8).
     """
 
-    def __init__(self, frames, height, width, world_size, device, group=None, wire="sparse", bg=(1.0, 1.0, 1.0)):
+    def __init__(self, frames, height, width, world_size, device, group=None, wire="sparse", bg=(1.0, 1.0, 1.0),
+                 algorithm="collective"):
         if wire not in ("sparse", "dense"):
             raise ValueError(f"wire must be 'sparse' or 'dense', got {wire!r}")
+        if algorithm not in ("collective", "direct"):
+            raise ValueError(f"algorithm must be 'collective' or 'direct', got {algorithm!r}")
+        self.algorithm = algorithm
         self.group = group
         self.world = world_size
         self.frames, self.height, self.width = frames, height, width
@@ -141,6 +145,27 @@ class FrameAllGather:
         """True when some step since calibrate() had more non-background tiles than the wire holds (synchronises)."""
         return self.wire == "sparse" and bool(int(self.status.item()))
 
+    def _gather(self, out_rows: torch.Tensor, local: torch.Tensor):
+        """out_rows [world, ...] <- every rank's `local`, enqueued on the current (side) stream.
+        "collective": RCCL's all-gather (its ring / tree choice).  "direct": one grouped send + receive per peer, i.e.
+        every rank writes its shard to its 7 peers over 7 distinct xGMI links at once -- the mesh form SURVEY.md
+        section 8(e) asks for; the bytes on each link are the same as in the best ring, without the 7 serial hops."""
+        if self.algorithm == "collective" or self.world == 1:
+            dist.all_gather_into_tensor(out_rows.view(-1), local.view(-1), group=self.group)
+            return
+        rank = dist.get_rank(self.group)
+        if local.is_cuda and dist.get_backend(self.group) != "nccl":
+            torch.cuda.current_stream(local.device).synchronize()  # host-side backend: see send_frames()
+        peers = [(rank + k) % self.world for k in range(1, self.world)]  # staggered: no two ranks start on one target
+        ops_ = []
+        for peer in peers:
+            ops_.append(dist.P2POp(dist.isend, local, peer, self.group))
+            ops_.append(dist.P2POp(dist.irecv, out_rows[peer], peer, self.group))
+        reqs = dist.batch_isend_irecv(ops_)
+        out_rows[rank].copy_(local, non_blocking=True)
+        for req in reqs:
+            req.wait()  # RCCL: orders the current stream after the transfers (no host block); gloo: blocks
+
     # ---- one step ------------------------------------------------------------------------------------------------------
     def submit(self, rgba: torch.Tensor, tile_hint=None) -> torch.Tensor:
         """rgba: contiguous fp32 [..., H, W, 4] produced on the current stream.  Returns the (future) full sequence
@@ -161,11 +186,11 @@ class FrameAllGather:
         with torch.cuda.stream(self.stream):
             if self.wire == "dense":
                 ops.frames_to_rgb8(rgba.view(F, H, W, 4), out=self.local[i])
-                dist.all_gather_into_tensor(self.full[i], self.local[i], group=self.group)
+                self._gather(self.full[i].view(self.world, F, H, W, 3), self.local[i])
             else:
                 ops.frames_pack_tiles(rgba.view(F, H, W, 4), self.capacity, self.bg, wire=self.local[i],
                                       tile_hint=tile_hint)
-                dist.all_gather_into_tensor(self.gathered[i].view(-1), self.local[i], group=self.group)
+                self._gather(self.gathered[i], self.local[i])
                 ops.frames_unpack_tiles(self.gathered[i], self.world, F, H, W, self.capacity, out=self.full[i],
                                         status=self.status, state=self.tile_state[i])
         return self.full[i]

@@ -112,6 +112,8 @@ def parse():
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the workload timed on the CPU oracle")
     ap.add_argument("--chunks", type=int, default=1,
                     help="frame groups pipelined on separate HIP streams (1 is fastest; 2 costs 17 percent more time, 4 costs 56 percent)")
+    ap.add_argument("--exchange", choices=["collective", "direct"], default=os.environ.get("AMAV_EXCHANGE", "collective"),
+                    help="frame all-gather as RCCL's collective or as grouped peer-to-peer sends (mesh form)")
     ap.add_argument("--wire", choices=["sparse", "dense"], default="sparse",
                     help="N > 1 exchange format: non-background 16x16 tiles of the uint8 frames (lossless) or all of them")
     ap.add_argument("--workload", choices=["render", "full", "stress"], default="render",
@@ -428,7 +430,7 @@ def run_full_workload(args, device, world, rank, dist):
 
     fp = FullPath(args, device, rank, args.frames)
     F, N, H, W = args.frames, args.gaussians, args.image, args.image
-    gather = FrameAllGather(F, H, W, world, device, wire=args.wire) if dist is not None else None
+    gather = FrameAllGather(F, H, W, world, device, wire=args.wire, algorithm=args.exchange) if dist is not None else None
     workspaces = fp.workspaces
 
     def step():
@@ -492,10 +494,12 @@ def exchange_description(gather):
     if gather is None:
         return "none"
     if gather.wire == "dense":
-        return {"collective": "RCCL all-gather of uint8 RGB frames", "bytes_per_rank_per_step": int(gather.local[0].numel())}
+        return {"collective": "RCCL all-gather of uint8 RGB frames", "algorithm": gather.algorithm,
+                "bytes_per_rank_per_step": int(gather.local[0].numel())}
     return {"collective": "RCCL all-gather of the non-background 16x16 tiles of the uint8 RGB frames (lossless), "
                           "unpacked to dense frames on every rank",
-            "bytes_per_rank_per_step": gather.wire_bytes_per_rank(), "capacity_tiles": gather.capacity,
+            "algorithm": gather.algorithm, "bytes_per_rank_per_step": gather.wire_bytes_per_rank(),
+            "capacity_tiles": gather.capacity,
             "dense_bytes_per_rank_per_step": gather.frames * gather.height * gather.width * 3}
 
 
@@ -626,7 +630,7 @@ def main():
     tokens, smpl, cam = make_render_inputs(F, cfg, seed=42 + rank, device=device)
     smpl_tokens = torch.zeros(1, F, 1, 1, device=device)  # only its [B,T] shape is read when no decoder is attached
     workspaces = [None] * max(1, min(args.chunks, F))  # filled by the first step, then reused
-    gather = FrameAllGather(F, H, W, world, device, wire=args.wire) if dist is not None else None
+    gather = FrameAllGather(F, H, W, world, device, wire=args.wire, algorithm=args.exchange) if dist is not None else None
 
     import audio_motion_avatar_amd.renderer as R
 

@@ -39,8 +39,8 @@ def _worker(rank, world, port, out):
                 gens.append((shards, torch.cat([ops.frames_to_rgb8(s[0]) for s in shards])))
         assert not torch.equal(gens[0][1], gens[1][1])
         ok = {}
-        for wire in ("sparse", "dense"):
-            gather = FrameAllGather(F, H, W, world, "cuda", wire=wire)
+        for wire, algorithm in (("sparse", "collective"), ("dense", "collective"), ("sparse", "direct"), ("dense", "direct")):
+            gather = FrameAllGather(F, H, W, world, "cuda", wire=wire, algorithm=algorithm)
             if wire == "sparse":
                 gather.calibrate(gens[0][0][rank][0], headroom=2.0, tile_hint=gens[0][0][rank][1])
                 assert gather.tile_state[0] is not None  # W % 16 == 0: the differential unpack is what runs
@@ -52,7 +52,8 @@ def _worker(rank, world, port, out):
                 full = gather.submit(mine, tile_hint=hint if wire == "sparse" else None)
                 gather.wait()
                 torch.cuda.synchronize()
-                ok[wire] = bool(torch.equal(full, want)) and not gather.overflowed() and ok.get(wire, True)
+                key = f"{wire}/{algorithm}"
+                ok[key] = bool(torch.equal(full, want)) and not gather.overflowed() and ok.get(key, True)
         flags = [None] * world
         dist.all_gather_object(flags, ok)
         if rank == 0:
@@ -77,7 +78,7 @@ def test_two_ranks_exchange_their_shards():
         for p in procs:
             p.join(timeout=400)
     assert all(p.exitcode == 0 for p in procs)
-    assert flags == [{"sparse": True, "dense": True}] * 2
+    assert flags == [{"sparse/collective": True, "dense/collective": True, "sparse/direct": True, "dense/direct": True}] * 2
 
 
 def _harness_worker(rank, world, port, out):
