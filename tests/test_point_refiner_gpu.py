@@ -146,6 +146,29 @@ def test_network_matches_reference_run():
         assert err <= 1e-4 * max(1.0, float(ref.abs().max())), (ci, err)
 
 
+def test_degenerate_clouds_match_oracle():
+    """Edge cases of the serialisation: a cloud inside ONE voxel (depth 0: no pooling shift, every tap empty), a
+    two-voxel cloud (depth 1), and a ragged pair of tiny clouds smaller than one MFMA tile."""
+    from oracle import ptv3 as o_pt
+
+    a, meta, _ = ref_fixture("ptv3")
+    net = _reference_net(meta)
+    p = {"pe.point_transformer." + k: v for k, v in seeded_params(meta["params"], "point_encoder.point_transformer.").items()}
+    g = torch.Generator().manual_seed(31)
+    N = 24
+    one_voxel = torch.rand(N, 3, generator=g) * 0.009 + 0.5          # floor(100 p) identical for all points
+    two_voxels = one_voxel.clone()
+    two_voxels[N // 2:, 1] += 0.01
+    spread = torch.randn(N, 3, generator=g) * 0.05
+    pts = torch.stack([one_voxel, two_voxels, spread])
+    feat = torch.randn(3, N, meta["cfg"]["in_channels"], generator=g)
+    assert [int(o_pt.frame_grid(c).max()).bit_length() for c in pts][:2] == [0, 1]
+    got = net(pts.cuda(), feat.cuda()).cpu()
+    want = o_pt.encoder_forward(p, "pe.", pts, feat, meta["cfg"])
+    assert torch.isfinite(got).all()
+    assert (got - want).abs().max() <= 1e-4 * max(1.0, float(want.abs().max()))
+
+
 def test_batched_clouds_equal_single_clouds():
     """Clouds of one pass do not see each other: a batch of clouds == each cloud alone (definition 2), and vs oracle."""
     from oracle import ptv3 as o_pt
@@ -181,7 +204,7 @@ def test_renderer_with_point_refiner_matches_oracle():
                          predict_smplx_params=False, no_point_refiner=False, num_gaussians=1500, refiner_clouds_per_pass=2,
                          **pcfg)
     r = init_random_heads(Renderer(cfg).eval(), std=0.05)
-    assert float(r.point_refiner[-1].weight.abs().max()) == 0.0  # renderer.py:46-47
+    assert float(r.point_refiner[-1].weight.detach().abs().max()) == 0.0  # renderer.py:46-47
     with torch.no_grad():
         r.point_refiner[-1].weight.normal_(0, 0.02)
         for m in r.point_encoder.modules():
