@@ -30,6 +30,7 @@ from .dist import all_gather_frames, recv_frames, send_frames, shard_range
 from .renderer import Renderer
 from .smplx_decoder import SMPLXDecoder
 from .triplane_audio_net import AudioTriplaneNet
+from .tuning import use_tuned_gemms
 
 
 class AudioDrivenAvatar(nn.Module):
@@ -37,6 +38,7 @@ class AudioDrivenAvatar(nn.Module):
         super().__init__()
         self.cfg = cfg or ModelConfig()
         rcfg = self.cfg.renderer
+        use_tuned_gemms()  # library kernel selection for the transformer's fixed GEMM shapes (tuning.py)
         self.smpl_decoder = SMPLXDecoder(rcfg)
         # one Renderer shared by both stages, as in the reference (lightning_model_wrapper.py:405-406)
         self.renderer = Renderer(rcfg, smpl_decoder=self.smpl_decoder)

@@ -282,9 +282,8 @@ class PointTransformerV3(nn.Module):
 
     @torch.no_grad()
     def forward(self, points, feat):
-        """points [F,N,3], feat [F,N,C_in] (fp32, HIP device) -> [F*N, dec_channels[0]] in the input's point order."""
-        if torch.is_grad_enabled():  # pragma: no cover (no_grad above)
-            raise NotImplementedError
+        """points [F,N,3], feat [F,N,C_in] (fp32, HIP device) -> [F*N, dec_channels[0]] in the input's point order.
+        Inference only (runs under no_grad: the HIP kernels have no backward)."""
         Fc, N, _ = points.shape
         n = Fc * N
         dev = points.device
@@ -319,6 +318,9 @@ class PTv3Encoder(nn.Module):
 
     def __init__(self, cfg=None):
         super().__init__()
+        from .tuning import use_tuned_gemms
+
+        use_tuned_gemms()  # library kernel selection for the fixed level-0 GEMM shapes (tuning.py)
         in_channels = getattr(cfg, "input_dim", None) or 3 * cfg.triplane_feature_dim  # ptv3_encoder.yaml:5
         self.point_transformer = PointTransformerV3(
             in_channels=in_channels, stride=cfg.stride, enc_channels=cfg.enc_channels, enc_depths=cfg.enc_depths,

@@ -112,6 +112,19 @@ class BasicTransformerBlock(nn.Module):
         self.norm3 = nn.LayerNorm(dim)
         self.ff = FeedForward(dim, dropout=dropout)
 
+    def forward_fused(self, h, pending, row):
+        """Inference path of Transformer1D_nn: `pending` is the previous block's feed-forward output whose residual add
+        has not happened yet (None for the first block), `row` [B,1,dim] this block's cross-attention output (one row per
+        batch item: a single audio key).  -> (h, pending) with the same meaning.  Three residual adds and two
+        LayerNorms run as two passes (ops.add_layernorm) instead of five."""
+        if pending is None:
+            n1 = self.norm1(h)
+        else:
+            h, n1 = ops.add_layernorm(h, pending, None, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        a1 = self.attn1(n1).contiguous()
+        h, n3 = ops.add_layernorm(h, a1, row, self.norm3.weight, self.norm3.bias, self.norm3.eps)
+        return h, self.ff(n3)
+
     def forward(self, hidden_states, encoder_hidden_states=None):
         h = hidden_states
         single_key = encoder_hidden_states is not None and encoder_hidden_states.shape[1] == 1
@@ -147,13 +160,40 @@ class Transformer1D_nn(nn.Module):
             BasicTransformerBlock(inner, num_attention_heads, attention_head_dim, dropout, cross_attention_dim)
             for _ in range(num_layers)])
         self.proj_out = nn.Linear(inner, in_channels)
+        self._cross = None
+
+    def _cross_rows(self, context):
+        """Cross-attention outputs of ALL blocks for a single-key context [B,1,ctx]: softmax over one key is 1, so block
+        l contributes to_out_l(to_v_l(context)) to every token.  Two batched products over the stacked weights instead
+        of two tiny GEMVs inside every block.  -> [L,B,1,dim]"""
+        mods = [b.attn2 for b in self.transformer_blocks]
+        tensors = [t for m in mods for t in (m.to_v.weight, m.to_out[0].weight, m.to_out[0].bias)]
+        version = tuple((t._version, t.data_ptr()) for t in tensors)
+        if self._cross is None or self._cross[0] != version:
+            wv = torch.stack([m.to_v.weight.detach().t() for m in mods]).contiguous()        # [L,ctx,inner]
+            wo = torch.stack([m.to_out[0].weight.detach().t() for m in mods]).contiguous()   # [L,inner,dim]
+            bo = torch.stack([m.to_out[0].bias.detach() for m in mods])[:, None, :].contiguous()  # [L,1,dim]
+            self._cross = (version, wv, wo, bo)
+        _, wv, wo, bo = self._cross
+        ctx = context[:, 0].unsqueeze(0).expand(len(mods), -1, -1)                           # [L,B,ctx]
+        return torch.baddbmm(bo, torch.bmm(ctx, wv), wo).unsqueeze(2)
 
     def forward(self, hidden_states, encoder_hidden_states=None):
         batch, channels, seq_len = hidden_states.shape
         residual = hidden_states
         h = self.norm(hidden_states).permute(0, 2, 1)
         h = self.proj_in(h)
-        for block in self.transformer_blocks:
-            h = block(h, encoder_hidden_states)
+        ctx = encoder_hidden_states
+        if (ctx is not None and ctx.shape[1] == 1 and h.is_cuda and h.dtype == torch.float32
+                and not torch.is_grad_enabled() and h.shape[-1] in (256, 512, 768, 1024)
+                and all(m.attn2.to_v.bias is None for m in self.transformer_blocks)):
+            rows = self._cross_rows(ctx)
+            h, pending = h.contiguous(), None
+            for block, row in zip(self.transformer_blocks, rows):
+                h, pending = block.forward_fused(h, pending, row)
+            h = pending + h
+        else:
+            for block in self.transformer_blocks:
+                h = block(h, ctx)
         h = self.proj_out(h).permute(0, 2, 1)
         return h + residual

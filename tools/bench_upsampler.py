@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Diagnostic: time of the TriplaneUpsampler (renderer.py:377-417) at the reference defaults (4 blocks, C=256,
+32^2 -> 512^2, three planes per frame) and of the default-config frame (upsampler + refiner at 30 000 points).
+
+    python tools/bench_upsampler.py [frames]
+"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from audio_motion_avatar_amd.config import RendererConfig  # noqa: E402
+from audio_motion_avatar_amd.renderer import Renderer  # noqa: E402
+from audio_motion_avatar_amd.synthetic import init_random_heads, make_render_inputs  # noqa: E402
+
+F = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+cfg = RendererConfig(image_size=(512, 512), subdivide_steps=0, predict_smplx_params=False, upsample_triplane=True,
+                     num_upsample_blocks=4, device="cuda")
+r = init_random_heads(Renderer(cfg).eval())
+tokens, smpl, cam = make_render_inputs(F, cfg, seed=42)
+up = r.triplane_upsampler
+
+
+def flops():
+    c, res, total = cfg.triplane_feature_dim, cfg.triplane_resolution, 0.0
+    for i in range(cfg.num_upsample_blocks):
+        res *= 2
+        total += 3 * (2.0 * res * res * c * c * 9) + (2.0 * (res // 2) ** 2 * c * c if i == 0 else 0.0)
+    return 3 * total  # three planes
+
+
+with torch.no_grad():
+    for _ in range(2):
+        out = up.forward_tokens(tokens[0], cfg.triplane_resolution)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        out = up.forward_tokens(tokens[0], cfg.triplane_resolution)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps / F
+print(f"TriplaneUpsampler: {dt * 1e3:.1f} ms per frame, {flops() / 1e12:.2f} TFLOP per frame -> {flops() / dt / 1e12:.1f} TFLOP/s; "
+      f"output {tuple(out.shape)}")
