@@ -51,6 +51,10 @@ def inverse_sigmoid(x):
     return torch.log(x / (1 - x)) if isinstance(x, torch.Tensor) else float(np.log(x / (1 - x)))
 
 
+class _WindowTooSmall(Exception):
+    """A refined point samples outside the exact region of the windowed upsampler (Renderer.forward falls back)."""
+
+
 class Renderer(nn.Module):
     def __init__(self, cfg=None, smpl_decoder=None):
         super().__init__()
@@ -198,6 +202,10 @@ class Renderer(nn.Module):
             if self.cfg.densify_smplx_verts:
                 vertices = ops.points_gather(vertices, self._gather_idx)
             points = self.refine_points(triplane_tokens, vertices)
+            bounds = getattr(self, "_window_bounds", None)
+            if bounds is not None and not self.triplane_upsampler.windows_contain(
+                    bounds, points, self.cfg.triplane_resolution, self.cfg.radius):
+                raise _WindowTooSmall()
             packed = ops.triplane_sample_decode(proj, points, transl, self.cfg.radius, w_point, out=out)
         elif self.cfg.densify_smplx_verts:
             packed = ops.triplane_sample_decode_indexed(proj, vertices, self._gather_idx, transl, self.cfg.radius,
@@ -277,8 +285,6 @@ class Renderer(nn.Module):
             raise AmavError("Renderer.forward needs smpl_tokens (the reference dereferences it too, renderer.py:84)")
         B, T = smpl_tokens.shape[:2]
         tokens = triplane_features.reshape(B * T, triplane_features.shape[2], triplane_features.shape[3]).float()
-        if getattr(self.cfg, "upsample_triplane", False):  # renderer.py:94-99 (library convolutions, 8(f) row 2)
-            tokens = self.triplane_upsampler.forward_tokens(tokens, self.cfg.triplane_resolution)
 
         pred_smpl_params = None
         if self.smpl_decoder is not None:
@@ -294,7 +300,25 @@ class Renderer(nn.Module):
             raise AmavError("Renderer.forward: no SMPL-X parameters (predict_smplx_params is off and no smpl_params_gt)")
 
         chunks = int(getattr(self.cfg, "pipeline_chunks", 1)) if B * T >= 32 else 1
-        rgba, packed = self.render_tokens(tokens, smpl_params, cam_params, chunks=chunks)
+        self._window_bounds = None
+        if getattr(self.cfg, "upsample_triplane", False):  # renderer.py:94-99 (library convolutions, 8(f) row 2)
+            up, R = self.triplane_upsampler, self.cfg.triplane_resolution
+            coarse = tokens
+            if getattr(self.cfg, "upsample_windows", True):
+                # only the texels the body's points can sample are upsampled (TriplaneUpsampler, "windowed evaluation")
+                refiner = hasattr(self, "point_encoder")
+                margin = float(getattr(self.cfg, "upsample_window_margin", 0.1)) if refiner else 0.0
+                windows, bounds = up.plan_windows(self.get_smpl_vertices(smpl_params), R, self.cfg.radius, margin)
+                tokens = up.forward_tokens_windowed(coarse, R, windows)
+                self._window_bounds = bounds if refiner else None  # refined points are checked against them
+            else:
+                tokens = up.forward_tokens(coarse, R)
+        try:
+            rgba, packed = self.render_tokens(tokens, smpl_params, cam_params, chunks=chunks)
+        except _WindowTooSmall:  # the refiner moved a point past the margin: full planes, once
+            self._window_bounds = None
+            tokens = self.triplane_upsampler.forward_tokens(coarse, self.cfg.triplane_resolution)
+            rgba, packed = self.render_tokens(tokens, smpl_params, cam_params, chunks=chunks)
         gaussians = self.unpack_gaussians(packed)
         rendered_images = rgba.view(B, T, *rgba.shape[1:])[..., :3]
         if self.cfg.predict_smplx_params:
@@ -360,6 +384,95 @@ class TriplaneUpsampler(nn.Module):
         planes = tokens.reshape(F, C, 3, resolution, resolution).permute(0, 2, 1, 3, 4)
         up = self.forward(planes)
         return up.permute(0, 2, 1, 3, 4).reshape(F, C, -1)
+
+    # ---- windowed evaluation -----------------------------------------------------------------------------------------
+    # The upsampled planes are only ever SAMPLED, at the body's points: a few per cent of the 512^2 texels of each plane.
+    # Convolutions are translation-equivariant, so each plane is cropped (at the input resolution) to the cells the
+    # sample points can reach plus a halo, upsampled, and written into its place of a full-resolution slab.  A crop
+    # border feeds zeros where the full plane has values; after n blocks of [nearest x2, three 3x3 convolutions] that
+    # error has travelled d_n = 2 d_(n-1) + 3 = 3 (2^n - 1) output texels (45 for n = 4, i.e. 3 input cells), so
+    # texels further inside are the full computation's values (identical operands, possibly another library kernel:
+    # rounding-level differences); where the crop touches the plane's own border the zero padding IS the reference's.
+    # At the reference defaults the windows cover ~25 % of the cells: 3.7 -> ~1 TFLOP per frame.
+    PLANE_AXES = ((0, 1), (0, 2), (1, 2))  # (width, height) coordinate of plane p (renderer.py:300-310)
+
+    def halo_texels(self):
+        return 3 * (2 ** len(self.upsample_blocks) - 1)
+
+    def _tap_range(self, coords, resolution, radius):
+        """Bilinear tap indices (first, second) at the upsampled resolution for coordinates in metres (grid_sample,
+        align_corners=False; renderer.py:298-310)."""
+        r_out = resolution * 2 ** len(self.upsample_blocks)
+        pix = ((torch.clamp(coords / radius, -1, 1) + 1) * r_out - 1) / 2
+        first = torch.floor(pix)
+        return first, first + 1, r_out
+
+    def plan_windows(self, points, resolution, radius, margin=0.0):
+        """points [F,N,3] -> (windows, bounds): per plane the crop (y0, y1, x0, x1) in input cells and the texel range
+        [ty0, ty1, tx0, tx1] (inclusive, upsampled resolution) inside which the windowed result equals the full one.
+        One host sync (the points' bounding box).  Window sizes only grow, in steps of 4 cells, so the library sees few
+        distinct convolution shapes."""
+        scale, halo = 2 ** len(self.upsample_blocks), self.halo_texels()
+        flat = points.reshape(-1, 3)
+        box = torch.stack([flat.amin(0) - margin, flat.amax(0) + margin]).cpu()
+        first, second, r_out = self._tap_range(box, resolution, radius)
+        t0 = first[0].clamp(0, r_out - 1).long().tolist()   # lowest / highest texel a tap can touch, per coordinate
+        t1 = second[1].clamp(0, r_out - 1).long().tolist()
+        if not hasattr(self, "_window_sizes"):
+            self._window_sizes = [[0, 0] for _ in range(3)]
+        windows, bounds = [], []
+        for p, (aw, ah) in enumerate(self.PLANE_AXES):
+            spans = []
+            for slot, axis in ((0, ah), (1, aw)):  # height first
+                c0 = max(0, (t0[axis] - halo) // scale)
+                c1 = min(resolution, (t1[axis] + halo) // scale + 1)
+                size = min(resolution, max(self._window_sizes[p][slot], -(-(c1 - c0) // 4) * 4))
+                self._window_sizes[p][slot] = size
+                start = min(max(0, c0 - (size - (c1 - c0)) // 2), resolution - size)
+                end = start + size
+                lo = 0 if start == 0 else start * scale + halo
+                hi = r_out - 1 if end == resolution else end * scale - 1 - halo
+                spans.append((start, end, lo, hi))
+            (y0, y1, ty0, ty1), (x0, x1, tx0, tx1) = spans
+            windows.append((y0, y1, x0, x1))
+            bounds.append((ty0, ty1, tx0, tx1))
+        return windows, bounds
+
+    def windows_contain(self, bounds, points, resolution, radius):
+        """True when every bilinear tap of `points` lies inside the exact region of its plane (host sync)."""
+        first, second, r_out = self._tap_range(points.reshape(-1, 3), resolution, radius)
+        lo_tap, hi_tap = first.clamp(0, r_out - 1).amin(0), second.clamp(0, r_out - 1).amax(0)
+        lo_tap, hi_tap = lo_tap.tolist(), hi_tap.tolist()
+        for (aw, ah), (ty0, ty1, tx0, tx1) in zip(self.PLANE_AXES, bounds):
+            if lo_tap[ah] < ty0 or hi_tap[ah] > ty1 or lo_tap[aw] < tx0 or hi_tap[aw] > tx1:
+                return False
+        return True
+
+    def _run(self, cur):
+        skip = cur
+        for block, skip_conn in zip(self.upsample_blocks, self.skip_connections):
+            skip = skip_conn(skip)
+            cur = block(cur) + skip
+        return cur
+
+    def forward_tokens_windowed(self, tokens, resolution, windows, out=None):
+        """Token slab [F,C,3 R^2] + plan_windows()' crops -> full-resolution slab [F,C,3 (2^n R)^2] whose texels inside
+        the windows' exact regions are the upsampled planes (the rest keeps whatever the slab held: never sampled)."""
+        F, C, _ = tokens.shape
+        scale = 2 ** len(self.upsample_blocks)
+        r_out = resolution * scale
+        if out is None:
+            cached = getattr(self, "_slab", None)
+            if cached is None or cached.shape != (F, C, 3 * r_out * r_out) or cached.device != tokens.device:
+                cached = torch.zeros(F, C, 3 * r_out * r_out, device=tokens.device)
+                self._slab = cached
+            out = cached
+        planes = tokens.view(F, C, 3, resolution, resolution)
+        ov = out.view(F, C, 3, r_out, r_out)
+        for p, (y0, y1, x0, x1) in enumerate(windows):
+            up = self._run(planes[:, :, p, y0:y1, x0:x1].contiguous())
+            ov[:, :, p, y0 * scale:y1 * scale, x0 * scale:x1 * scale] = up
+        return out
 
 
 ### Gaussian Splatting Renderer ###

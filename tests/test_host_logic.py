@@ -164,3 +164,58 @@ def test_reference_checkpoint_keeps_refiner_keys():
     bare = AudioDrivenAvatar(_small_model_cfg())
     res = bare.load_reference_checkpoint({"state_dict": state})  # refiner keys dropped, nothing missing
     assert not res.missing_keys and not res.unexpected_keys
+
+
+def test_windowed_upsampler_equals_full_planes_where_it_claims_to():
+    """TriplaneUpsampler.forward_tokens_windowed: inside the texel bounds plan_windows() reports, the cropped
+    evaluation equals the full one (3 (2^n - 1) texels of halo), incl. windows that touch the plane border, and
+    sampling at the points gives the same features (the only consumer of the planes)."""
+    from types import SimpleNamespace
+
+    from audio_motion_avatar_amd.renderer import TriplaneUpsampler
+    from oracle import triplane as o_tri
+
+    for n_blocks, R in ((2, 16), (3, 12)):
+        cfg = SimpleNamespace(triplane_feature_dim=8, num_upsample_blocks=n_blocks)
+        up = TriplaneUpsampler(cfg).eval()
+        for m in up.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.3)
+                m.running_var.uniform_(0.5, 1.5)
+        assert up.halo_texels() == 3 * (2 ** n_blocks - 1)
+        g = torch.Generator().manual_seed(n_blocks)
+        tokens = torch.randn(2, 8, 3 * R * R, generator=g)
+        radius = 1.4
+        with torch.no_grad():
+            full = up.forward_tokens(tokens, R)
+            r_out = R * 2 ** n_blocks
+            fv = full.view(2, 8, 3, r_out, r_out)
+            # a body-like box off centre, one that touches the -x / +z borders, and one that needs every cell
+            for lo, hi in (((-0.25, -0.7, -0.1), (0.3, 0.6, 0.2)), ((-1.4, -0.2, 0.9), (-1.0, 0.1, 1.4)),
+                           ((-1.3, -1.3, -1.3), (1.3, 1.3, 1.3))):
+                up._window_sizes = [[0, 0] for _ in range(3)]
+                pts = torch.rand(2, 300, 3, generator=g) * (torch.tensor(hi) - torch.tensor(lo)) + torch.tensor(lo)
+                windows, bounds = up.plan_windows(pts, R, radius)
+                assert up.windows_contain(bounds, pts, R, radius)
+                got = up.forward_tokens_windowed(tokens, R, windows, out=torch.full_like(full, float("nan")))
+                gv = got.view(2, 8, 3, r_out, r_out)
+                for p, (ty0, ty1, tx0, tx1) in enumerate(bounds):
+                    a, b = gv[:, :, p, ty0:ty1 + 1, tx0:tx1 + 1], fv[:, :, p, ty0:ty1 + 1, tx0:tx1 + 1]
+                    assert torch.isfinite(a).all() and (a - b).abs().max() <= 1e-5, (n_blocks, p)
+                planes_w = o_tri.tokens_to_planes(torch.nan_to_num(got)[None], r_out)
+                planes_f = o_tri.tokens_to_planes(full[None], r_out)
+                fw = o_tri.sample_from_triplane(planes_w, pts, radius)
+                ff = o_tri.sample_from_triplane(planes_f, pts, radius)
+                assert (fw - ff).abs().max() <= 1e-5
+                # a point outside the planned box is reported
+                far = pts.clone()
+                far[0, 0] = torch.tensor(hi) + torch.tensor([0.5, 0.5, -0.5])
+                cover_all = all(w == (0, R, 0, R) for w in windows)
+                assert up.windows_contain(bounds, far, R, radius) == cover_all
+            # sizes only grow
+            up._window_sizes = [[0, 0] for _ in range(3)]
+            w_small, _ = up.plan_windows(torch.zeros(1, 4, 3), R, radius)
+            w_big, _ = up.plan_windows(torch.tensor([[[-0.9, -0.9, -0.9], [0.9, 0.9, 0.9]]]), R, radius)
+            w_again, _ = up.plan_windows(torch.zeros(1, 4, 3), R, radius)
+            size = lambda w: [(y1 - y0, x1 - x0) for y0, y1, x0, x1 in w]
+            assert size(w_again) == size(w_big) and size(w_small) != size(w_big)

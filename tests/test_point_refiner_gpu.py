@@ -231,3 +231,42 @@ def test_renderer_with_point_refiner_matches_oracle():
         assert (gaussians[k].cpu() - g[k]).abs().max() <= 1e-4, k
     assert images.shape == (1, F_, 64, 64, 3)
 
+
+
+def test_windowed_upsampler_with_refiner_and_fallback():
+    """upsample_triplane + point refiner: the windowed upsampler (planes cropped to what the points can sample) gives
+    the Gaussians of the full-plane evaluation; when the refiner moves points past the planned margin the renderer
+    notices and falls back to full planes."""
+    from audio_motion_avatar_amd.config import RendererConfig
+    from audio_motion_avatar_amd.renderer import Renderer
+    from audio_motion_avatar_amd.synthetic import init_random_heads, make_render_inputs
+
+    pcfg = dict(stride=(2,), enc_depths=(1, 1), enc_channels=(32, 64), enc_num_head=(2, 4), enc_patch_size=(256, 256),
+                dec_depths=(1,), dec_channels=(32,), dec_num_head=(2,), dec_patch_size=(256,))
+    base = dict(image_size=(64, 64), subdivide_steps=0, triplane_feature_dim=16, triplane_resolution=16,
+                predict_smplx_params=False, no_point_refiner=False, num_gaussians=1200, upsample_triplane=True,
+                num_upsample_blocks=2, radius=2.8, **pcfg)   # radius 2.8: the body fills a quarter of the planes
+    r_win = init_random_heads(Renderer(RendererConfig(upsample_windows=True, **base)).eval(), std=0.05)
+    r_full = Renderer(RendererConfig(upsample_windows=False, **base)).eval()
+    r_full.load_state_dict(r_win.state_dict())
+    F_ = 2
+    tokens, smpl, cam = make_render_inputs(F_, r_win.cfg, seed=9)
+    dummy = torch.zeros(1, F_, 1, 1, device="cuda")
+    for shift, expect_fallback in ((0.02, False), (1.5, True)):  # metres; the planned margin is 0.1 m + cell rounding
+        with torch.no_grad():
+            for r in (r_win, r_full):
+                r.point_refiner[-1].weight.normal_(0, 1, generator=None).mul_(0)
+                r.point_refiner[-1].bias.fill_(shift)                 # a uniform shift of every point
+            r_full.load_state_dict(r_win.state_dict())
+            calls = []
+            orig = r_win.triplane_upsampler.forward_tokens
+            r_win.triplane_upsampler.forward_tokens = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+            _, g_win = r_win(tokens, cam, dummy, smpl)
+            r_win.triplane_upsampler.forward_tokens = orig
+            _, g_full = r_full(tokens, cam, dummy, smpl)
+        assert bool(calls) == expect_fallback, (shift, calls)
+        if not expect_fallback:
+            w = r_win.triplane_upsampler._window_sizes
+            assert all(s < 16 for pair in w for s in pair), w     # really cropped
+        for k in ("xyz", "scale", "rot", "opacity", "color"):
+            assert (g_win[k] - g_full[k]).abs().max() <= 2e-5, (shift, k)
