@@ -241,12 +241,24 @@ __global__ __launch_bounds__(256) void pair_gemm_kernel(const float *__restrict_
         if (k0 + KC < Cin) AMAV_PG_LOAD(k0 + KC)
         const float *arow_l = &As[(wave * 32 + c) * LDA + hh];
         const float *brow_l = &Bs[hh * LDB + c];
+        // operands of k-step s + 1 are read from LDS before the MFMAs of step s issue (read just in time, every MFMA
+        // group waited a full LDS round trip: ds_read; s_waitcnt 0; mfma ...); the order is pinned, as in attention.hip
+        float av[2], bv[2][NACC];
+        av[0] = arow_l[0];
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) bv[0][a] = brow_l[32 * a];
 #pragma unroll
         for (int s = 0; s < KC / 2; ++s) {
-            const float av = arow_l[2 * s];
+            if (s + 1 < KC / 2) {
+                av[(s + 1) & 1] = arow_l[2 * (s + 1)];
+#pragma unroll
+                for (int a = 0; a < NACC; ++a) bv[(s + 1) & 1][a] = brow_l[2 * (s + 1) * LDB + 32 * a];
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int a = 0; a < NACC; ++a)
-                acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, brow_l[2 * s * LDB + 32 * a], acc[a], 0, 0, 0);
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1], bv[s & 1][a], acc[a], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
     }
@@ -292,7 +304,7 @@ __global__ __launch_bounds__(256) void pair_sum_kernel(long long n, int taps, in
 // One workgroup = 128 queries of one (patch, head); S^T = K Q^T and O^T = V^T P^T on v_mfma_f32_32x32x2_f32 with the
 // probabilities kept in registers (layout notes: attention.hip).
 template <int D>
-__global__ __launch_bounds__(256) void patch_attention_kernel(const float *__restrict__ qkv,
+__global__ __launch_bounds__(256, 3) void patch_attention_kernel(const float *__restrict__ qkv,
                                                               const long long *__restrict__ order,
                                                               const int4 *__restrict__ desc, float *__restrict__ out,
                                                               int C, float scale_log2e) {
@@ -361,11 +373,24 @@ __global__ __launch_bounds__(256) void patch_attention_kernel(const float *__res
         f32x16 S0, S1;
 #pragma unroll
         for (int t = 0; t < 16; ++t) S0[t] = 0.f, S1[t] = 0.f;
+        // K operands of step s + 2 are read before the MFMAs of step s issue; order pinned (see attention.hip)
+        float ka[2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            ka[u][0] = Kt[(2 * u + hh) * kLdk + c];
+            ka[u][1] = Kt[(2 * u + hh) * kLdk + 32 + c];
+        }
 #pragma unroll
         for (int s = 0; s < D / 2; ++s) {
-            const float a0 = Kt[(2 * s + hh) * kLdk + c], a1 = Kt[(2 * s + hh) * kLdk + 32 + c];
+            const float a0 = ka[s & 1][0], a1 = ka[s & 1][1];
+            if (s + 2 < D / 2) {
+                ka[s & 1][0] = Kt[(2 * (s + 2) + hh) * kLdk + c];
+                ka[s & 1][1] = Kt[(2 * (s + 2) + hh) * kLdk + 32 + c];
+            }
+            __builtin_amdgcn_sched_barrier(0);
             S0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, Qr[s], S0, 0, 0, 0);
             S1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, Qr[s], S1, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if ((kt + 1) * 64 > K) {  // accumulator register t of key half kb: key kt*64 + 32 kb + (t&3) + 8 (t>>2) + 4 hh
 #pragma unroll
@@ -389,14 +414,32 @@ __global__ __launch_bounds__(256) void patch_attention_kernel(const float *__res
 #pragma unroll
             for (int t = 0; t < 16; ++t) O[a][t] *= corr;
 
-        float psum = 0.f;
+        // V operands of step u + 2 are read and the probability of step u + 1 is exponentiated before the MFMAs of
+        // step u issue: the LDS round trip and the quarter-rate exp run under the matrix pipe
+        auto vrow = [&](int u) { return ((u >> 4) * 32 + (u & 3) + 8 * ((u & 15) >> 2) + 4 * hh) * DV + c; };
+        auto score = [&](int u) { return (u < 16 ? S0[u] : S1[u - 16]) - m_new; };
+        float va[3][NO];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int a = 0; a < NO; ++a) va[u][a] = Vs[vrow(u) + 32 * a];
+        float p_cur = __builtin_amdgcn_exp2f(score(0)), psum = 0.f;
 #pragma unroll
         for (int u = 0; u < 32; ++u) {
-            const float p = __builtin_amdgcn_exp2f((u < 16 ? S0[u] : S1[u - 16]) - m_new);
-            psum += p;
-            const int vr = ((u >> 4) * 32 + (u & 3) + 8 * ((u & 15) >> 2) + 4 * hh) * DV + c;
+            const float pu = p_cur;
+            float vu[NO];
 #pragma unroll
-            for (int a = 0; a < NO; ++a) O[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[vr + 32 * a], p, O[a], 0, 0, 0);
+            for (int a = 0; a < NO; ++a) vu[a] = va[u % 3][a];
+            if (u + 2 < 32) {
+#pragma unroll
+                for (int a = 0; a < NO; ++a) va[(u + 2) % 3][a] = Vs[vrow(u + 2) + 32 * a];
+            }
+            if (u + 1 < 32) p_cur = __builtin_amdgcn_exp2f(score(u + 1));
+            psum += pu;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int a = 0; a < NO; ++a) O[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(vu[a], pu, O[a], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         l_run = l_run * corr + psum;
         __syncthreads();
