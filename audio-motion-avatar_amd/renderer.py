@@ -308,9 +308,9 @@ class Renderer(nn.Module):
                 # only the texels the body's points can sample are upsampled (TriplaneUpsampler, "windowed evaluation")
                 refiner = hasattr(self, "point_encoder")
                 margin = float(getattr(self.cfg, "upsample_window_margin", 0.1)) if refiner else 0.0
-                windows, bounds = up.plan_windows(self.get_smpl_vertices(smpl_params), R, self.cfg.radius, margin)
-                tokens = up.forward_tokens_windowed(coarse, R, windows)
-                self._window_bounds = bounds if refiner else None  # refined points are checked against them
+                plan = up.plan_windows(self.get_smpl_vertices(smpl_params), R, self.cfg.radius, margin)
+                tokens = up.forward_tokens_windowed(coarse, R, plan)
+                self._window_bounds = plan if refiner else None  # refined points are checked against it
             else:
                 tokens = up.forward_tokens(coarse, R)
         try:
@@ -387,79 +387,107 @@ class TriplaneUpsampler(nn.Module):
 
     # ---- windowed evaluation -----------------------------------------------------------------------------------------
     # The upsampled planes are only ever SAMPLED, at the body's points: a few per cent of the 512^2 texels of each plane.
-    # Convolutions are translation-equivariant, so each plane is cropped (at the input resolution) to the cells the
-    # sample points can reach plus a halo, upsampled, and written into its place of a full-resolution slab.  A crop
-    # border feeds zeros where the full plane has values; after n blocks of [nearest x2, three 3x3 convolutions] that
-    # error has travelled d_n = 2 d_(n-1) + 3 = 3 (2^n - 1) output texels (45 for n = 4, i.e. 3 input cells), so
-    # texels further inside are the full computation's values (identical operands, possibly another library kernel:
-    # rounding-level differences); where the crop touches the plane's own border the zero padding IS the reference's.
-    # At the reference defaults the windows cover ~25 % of the cells: 3.7 -> ~1 TFLOP per frame.
+    # Convolutions are translation-equivariant, so only what the sample points can reach is computed, in two stages:
+    #   * blocks 1 .. n-1 (a quarter of the flops) run on ONE crop per plane: the bounding box (in input cells) of the
+    #     active tiles plus a 3-cell halo.  A crop border feeds zeros where the full plane has values; after k blocks
+    #     of [nearest x2, three 3x3 convolutions] that error has travelled d_k = 2 d_(k-1) + 3 = 3 (2^k - 1) texels;
+    #   * the last block (three quarters of the flops) runs on the ACTIVE TILES only: output tiles of 4 x 4 input
+    #     cells (64 x 64 texels for n = 4) that contain a bilinear tap of some point, each cut out of the level-(n-1)
+    #     activation with a 2-texel halo (the block's own reach is 3 output texels), batched through the library's
+    #     convolutions and written into their place of the full-resolution slab.
+    # Texels inside active tiles are the full computation's values (identical operands, possibly another library
+    # kernel: rounding-level differences); the rest of the slab keeps whatever it held and is never sampled.  Where a
+    # crop coincides with the plane's own border the zero padding IS the reference's; a tile whose halo would cross
+    # the plane's border makes its plane take the last block on the whole crop instead.  Crop sizes and tile-batch
+    # sizes only grow (steps of 4 cells / 8 tiles), so the library sees few distinct convolution shapes.
     PLANE_AXES = ((0, 1), (0, 2), (1, 2))  # (width, height) coordinate of plane p (renderer.py:300-310)
+    TILE_CELLS = 4
 
-    def halo_texels(self):
-        return 3 * (2 ** len(self.upsample_blocks) - 1)
+    def halo_texels(self, blocks=None):
+        return 3 * (2 ** (len(self.upsample_blocks) if blocks is None else blocks) - 1)
 
-    def _tap_range(self, coords, resolution, radius):
-        """Bilinear tap indices (first, second) at the upsampled resolution for coordinates in metres (grid_sample,
-        align_corners=False; renderer.py:298-310)."""
+    def _taps(self, coords, resolution, radius):
+        """First / second bilinear tap index at the upsampled resolution, clamped into the plane (grid_sample,
+        align_corners=False; renderer.py:298-310).  A tap outside the plane reads the zero padding: nothing to compute."""
         r_out = resolution * 2 ** len(self.upsample_blocks)
         pix = ((torch.clamp(coords / radius, -1, 1) + 1) * r_out - 1) / 2
         first = torch.floor(pix)
-        return first, first + 1, r_out
+        return first.clamp(0, r_out - 1).long(), (first + 1).clamp(0, r_out - 1).long(), r_out
+
+    def _active_tiles(self, points, resolution, radius, margin):
+        """bool [3, g, g] (plane, tile row, tile column), g = resolution / TILE_CELLS: tiles holding a tap of a point
+        (or of the point displaced by up to `margin` metres along every axis)."""
+        g = resolution // self.TILE_CELLS
+        tile = self.TILE_CELLS * 2 ** len(self.upsample_blocks)
+        flat = points.reshape(-1, 3)
+        lo, _, _ = self._taps(flat - margin, resolution, radius)
+        _, hi, _ = self._taps(flat + margin, resolution, radius)
+        lo, hi = lo // tile, hi // tile                     # [M,3] tile index per coordinate
+        mask = torch.zeros(3, g, g, dtype=torch.bool, device=points.device)
+        span = int((hi - lo).max()) if flat.shape[0] else 0   # (host sync) usually 1: a tap pair straddles a tile edge
+        for p, (aw, ah) in enumerate(self.PLANE_AXES):
+            for dy in range(span + 1):
+                for dx in range(span + 1):
+                    mask[p, torch.minimum(lo[:, ah] + dy, hi[:, ah]), torch.minimum(lo[:, aw] + dx, hi[:, aw])] = True
+        return mask
 
     def plan_windows(self, points, resolution, radius, margin=0.0):
-        """points [F,N,3] -> (windows, bounds): per plane the crop (y0, y1, x0, x1) in input cells and the texel range
-        [ty0, ty1, tx0, tx1] (inclusive, upsampled resolution) inside which the windowed result equals the full one.
-        One host sync (the points' bounding box).  Window sizes only grow, in steps of 4 cells, so the library sees few
-        distinct convolution shapes."""
-        scale, halo = 2 ** len(self.upsample_blocks), self.halo_texels()
-        flat = points.reshape(-1, 3)
-        box = torch.stack([flat.amin(0) - margin, flat.amax(0) + margin]).cpu()
-        first, second, r_out = self._tap_range(box, resolution, radius)
-        t0 = first[0].clamp(0, r_out - 1).long().tolist()   # lowest / highest texel a tap can touch, per coordinate
-        t1 = second[1].clamp(0, r_out - 1).long().tolist()
+        """points [F,N,3] -> plan: per plane {crop (y0,y1,x0,x1) in input cells, tiles [(ty,tx)...] or None (last block
+        on the whole crop), mask}.  Host syncs: the tile mask."""
+        n = len(self.upsample_blocks)
+        R = resolution
         if not hasattr(self, "_window_sizes"):
             self._window_sizes = [[0, 0] for _ in range(3)]
-        windows, bounds = [], []
-        for p, (aw, ah) in enumerate(self.PLANE_AXES):
+        finite = bool(torch.isfinite(points).all())
+        if R % self.TILE_CELLS or not finite:  # no tiling / a diverged pose: whole planes
+            return [dict(crop=(0, R, 0, R), tiles=None, mask=None) for _ in range(3)]
+        mask = self._active_tiles(points, R, radius, margin).cpu()
+        halo_cells = 3 if n >= 2 else 2
+        s_in = 2 ** (n - 1)                 # texels per input cell at the last block's input
+        plan = []
+        for p in range(3):
+            ys, xs = torch.nonzero(mask[p], as_tuple=True)
+            if ys.numel() == 0:
+                plan.append(dict(crop=(0, self.TILE_CELLS, 0, self.TILE_CELLS), tiles=[], mask=mask[p]))
+                continue
             spans = []
-            for slot, axis in ((0, ah), (1, aw)):  # height first
-                c0 = max(0, (t0[axis] - halo) // scale)
-                c1 = min(resolution, (t1[axis] + halo) // scale + 1)
-                size = min(resolution, max(self._window_sizes[p][slot], -(-(c1 - c0) // 4) * 4))
+            for slot, idx in ((0, ys), (1, xs)):
+                c0 = max(0, int(idx.min()) * self.TILE_CELLS - halo_cells)
+                c1 = min(R, (int(idx.max()) + 1) * self.TILE_CELLS + halo_cells)
+                size = min(R, max(self._window_sizes[p][slot], -(-(c1 - c0) // 4) * 4))
                 self._window_sizes[p][slot] = size
-                start = min(max(0, c0 - (size - (c1 - c0)) // 2), resolution - size)
-                end = start + size
-                lo = 0 if start == 0 else start * scale + halo
-                hi = r_out - 1 if end == resolution else end * scale - 1 - halo
-                spans.append((start, end, lo, hi))
-            (y0, y1, ty0, ty1), (x0, x1, tx0, tx1) = spans
-            windows.append((y0, y1, x0, x1))
-            bounds.append((ty0, ty1, tx0, tx1))
-        return windows, bounds
+                start = min(max(0, c0 - (size - (c1 - c0)) // 2), R - size)
+                spans.append((start, start + size))
+            (y0, y1), (x0, x1) = spans
+            tiles = list(zip(ys.tolist(), xs.tolist()))
+            t_in = self.TILE_CELLS * s_in
+            inside = all(ty * t_in - 2 >= 0 and (ty + 1) * t_in + 2 <= R * s_in and tx * t_in - 2 >= 0
+                         and (tx + 1) * t_in + 2 <= R * s_in for ty, tx in tiles)
+            plan.append(dict(crop=(y0, y1, x0, x1), tiles=tiles if inside else None, mask=mask[p]))
+        return plan
 
-    def windows_contain(self, bounds, points, resolution, radius):
-        """True when every bilinear tap of `points` lies inside the exact region of its plane (host sync)."""
-        first, second, r_out = self._tap_range(points.reshape(-1, 3), resolution, radius)
-        lo_tap, hi_tap = first.clamp(0, r_out - 1).amin(0), second.clamp(0, r_out - 1).amax(0)
-        lo_tap, hi_tap = lo_tap.tolist(), hi_tap.tolist()
-        for (aw, ah), (ty0, ty1, tx0, tx1) in zip(self.PLANE_AXES, bounds):
-            if lo_tap[ah] < ty0 or hi_tap[ah] > ty1 or lo_tap[aw] < tx0 or hi_tap[aw] > tx1:
-                return False
-        return True
+    def windows_contain(self, plan, points, resolution, radius):
+        """True when every bilinear tap of `points` lies where the planned evaluation is exact (host sync)."""
+        if all(w["mask"] is None for w in plan):
+            return True
+        need = self._active_tiles(points, resolution, radius, 0.0).cpu()
+        return all(w["mask"] is None or not bool((need[p] & ~w["mask"]).any()) for p, w in enumerate(plan))
 
-    def _run(self, cur):
-        skip = cur
-        for block, skip_conn in zip(self.upsample_blocks, self.skip_connections):
+    def _run(self, cur, first=0, last=None, skip=None):
+        """Blocks first .. last-1 on [B,C,h,w]; returns (activation, skip chain) at the output resolution."""
+        skip = cur if skip is None else skip
+        blocks = list(zip(self.upsample_blocks, self.skip_connections))[first:last]
+        for block, skip_conn in blocks:
             skip = skip_conn(skip)
             cur = block(cur) + skip
-        return cur
+        return cur, skip
 
-    def forward_tokens_windowed(self, tokens, resolution, windows, out=None):
-        """Token slab [F,C,3 R^2] + plan_windows()' crops -> full-resolution slab [F,C,3 (2^n R)^2] whose texels inside
-        the windows' exact regions are the upsampled planes (the rest keeps whatever the slab held: never sampled)."""
+    def forward_tokens_windowed(self, tokens, resolution, plan, out=None):
+        """Token slab [F,C,3 R^2] + plan_windows()' plan -> full-resolution slab [F,C,3 (2^n R)^2] whose texels inside
+        the active tiles are the upsampled planes (the rest keeps whatever the slab held: never sampled)."""
         F, C, _ = tokens.shape
-        scale = 2 ** len(self.upsample_blocks)
+        n = len(self.upsample_blocks)
+        scale, s_in = 2 ** n, 2 ** (n - 1)
         r_out = resolution * scale
         if out is None:
             cached = getattr(self, "_slab", None)
@@ -469,9 +497,33 @@ class TriplaneUpsampler(nn.Module):
             out = cached
         planes = tokens.view(F, C, 3, resolution, resolution)
         ov = out.view(F, C, 3, r_out, r_out)
-        for p, (y0, y1, x0, x1) in enumerate(windows):
-            up = self._run(planes[:, :, p, y0:y1, x0:x1].contiguous())
-            ov[:, :, p, y0 * scale:y1 * scale, x0 * scale:x1 * scale] = up
+        if not hasattr(self, "_tile_batch"):
+            self._tile_batch = [0, 0, 0]
+        for p, w in enumerate(plan):
+            y0, y1, x0, x1 = w["crop"]
+            if w["tiles"] is not None and not w["tiles"]:
+                continue  # no point samples this plane
+            crop = planes[:, :, p, y0:y1, x0:x1].contiguous()
+            if w["tiles"] is None:
+                up, _ = self._run(crop)
+                ov[:, :, p, y0 * scale:y1 * scale, x0 * scale:x1 * scale] = up
+                continue
+            act, skip = self._run(crop, 0, n - 1)           # level n-1: [F,C,(y1-y0) s_in, (x1-x0) s_in]
+            t_in, t_out = self.TILE_CELLS * s_in, self.TILE_CELLS * scale
+            tiles = w["tiles"]
+            count = max(self._tile_batch[p], -(-len(tiles) // 8) * 8)
+            self._tile_batch[p] = count
+            xb = act.new_zeros(count, F, C, t_in + 4, t_in + 4)
+            sb = act.new_zeros(count, F, C, t_in, t_in)
+            for i, (ty, tx) in enumerate(tiles):
+                r0, c0 = ty * t_in - y0 * s_in, tx * t_in - x0 * s_in
+                xb[i] = act[:, :, r0 - 2:r0 + t_in + 2, c0 - 2:c0 + t_in + 2]
+                sb[i] = skip[:, :, r0:r0 + t_in, c0:c0 + t_in]
+            block, skip_conn = self.upsample_blocks[n - 1], self.skip_connections[n - 1]
+            res = block(xb.view(count * F, C, t_in + 4, t_in + 4))[:, :, 4:-4, 4:-4]
+            res = (res + skip_conn(sb.view(count * F, C, t_in, t_in))).view(count, F, C, t_out, t_out)
+            for i, (ty, tx) in enumerate(tiles):
+                ov[:, :, p, ty * t_out:(ty + 1) * t_out, tx * t_out:(tx + 1) * t_out] = res[i]
         return out
 
 

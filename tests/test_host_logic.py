@@ -167,15 +167,16 @@ def test_reference_checkpoint_keeps_refiner_keys():
 
 
 def test_windowed_upsampler_equals_full_planes_where_it_claims_to():
-    """TriplaneUpsampler.forward_tokens_windowed: inside the texel bounds plan_windows() reports, the cropped
-    evaluation equals the full one (3 (2^n - 1) texels of halo), incl. windows that touch the plane border, and
-    sampling at the points gives the same features (the only consumer of the planes)."""
+    """TriplaneUpsampler.forward_tokens_windowed: inside the active tiles plan_windows() reports, the cropped / tiled
+    evaluation equals the full one (3 (2^k - 1) texels of halo after k blocks, 2 texels for the last block's tiles),
+    incl. tiles at the plane border (last block on the whole crop), and sampling at the points gives the same
+    features (the only consumer of the planes)."""
     from types import SimpleNamespace
 
     from audio_motion_avatar_amd.renderer import TriplaneUpsampler
     from oracle import triplane as o_tri
 
-    for n_blocks, R in ((2, 16), (3, 12)):
+    for n_blocks, R in ((1, 32), (2, 32), (3, 16)):
         cfg = SimpleNamespace(triplane_feature_dim=8, num_upsample_blocks=n_blocks)
         up = TriplaneUpsampler(cfg).eval()
         for m in up.modules():
@@ -186,36 +187,46 @@ def test_windowed_upsampler_equals_full_planes_where_it_claims_to():
         g = torch.Generator().manual_seed(n_blocks)
         tokens = torch.randn(2, 8, 3 * R * R, generator=g)
         radius = 1.4
+        tile = 4 * 2 ** n_blocks
         with torch.no_grad():
             full = up.forward_tokens(tokens, R)
             r_out = R * 2 ** n_blocks
             fv = full.view(2, 8, 3, r_out, r_out)
-            # a body-like box off centre, one that touches the -x / +z borders, and one that needs every cell
-            for lo, hi in (((-0.25, -0.7, -0.1), (0.3, 0.6, 0.2)), ((-1.4, -0.2, 0.9), (-1.0, 0.1, 1.4)),
-                           ((-1.3, -1.3, -1.3), (1.3, 1.3, 1.3))):
-                up._window_sizes = [[0, 0] for _ in range(3)]
+            # a body-like box off centre (tiles), one that touches the -x / +z borders (whole crop), one that needs all
+            for case, (lo, hi) in enumerate((((-0.25, -0.6, -0.1), (0.3, 0.55, 0.2)), ((-1.4, -0.2, 0.9), (-1.0, 0.1, 1.4)),
+                                             ((-1.3, -1.3, -1.3), (1.3, 1.3, 1.3)))):
+                up._window_sizes, up._tile_batch = [[0, 0] for _ in range(3)], [0, 0, 0]
                 pts = torch.rand(2, 300, 3, generator=g) * (torch.tensor(hi) - torch.tensor(lo)) + torch.tensor(lo)
-                windows, bounds = up.plan_windows(pts, R, radius)
-                assert up.windows_contain(bounds, pts, R, radius)
-                got = up.forward_tokens_windowed(tokens, R, windows, out=torch.full_like(full, float("nan")))
+                plan = up.plan_windows(pts, R, radius)
+                assert up.windows_contain(plan, pts, R, radius)
+                if case == 0:
+                    assert all(w["tiles"] for w in plan) and all(len(w["tiles"]) < (R // 4) ** 2 for w in plan)
+                if case == 1:
+                    assert any(w["tiles"] is None for w in plan)   # a halo would cross the plane border
+                got = up.forward_tokens_windowed(tokens, R, plan, out=torch.full_like(full, float("nan")))
                 gv = got.view(2, 8, 3, r_out, r_out)
-                for p, (ty0, ty1, tx0, tx1) in enumerate(bounds):
-                    a, b = gv[:, :, p, ty0:ty1 + 1, tx0:tx1 + 1], fv[:, :, p, ty0:ty1 + 1, tx0:tx1 + 1]
-                    assert torch.isfinite(a).all() and (a - b).abs().max() <= 1e-5, (n_blocks, p)
+                for p, w in enumerate(plan):
+                    for ty, tx in zip(*torch.nonzero(w["mask"], as_tuple=True)):
+                        a = gv[:, :, p, ty * tile:(ty + 1) * tile, tx * tile:(tx + 1) * tile]
+                        b = fv[:, :, p, ty * tile:(ty + 1) * tile, tx * tile:(tx + 1) * tile]
+                        assert torch.isfinite(a).all() and (a - b).abs().max() <= 1e-5, (n_blocks, case, p, int(ty), int(tx))
                 planes_w = o_tri.tokens_to_planes(torch.nan_to_num(got)[None], r_out)
                 planes_f = o_tri.tokens_to_planes(full[None], r_out)
                 fw = o_tri.sample_from_triplane(planes_w, pts, radius)
                 ff = o_tri.sample_from_triplane(planes_f, pts, radius)
                 assert (fw - ff).abs().max() <= 1e-5
-                # a point outside the planned box is reported
+                # a point outside the planned tiles is reported
                 far = pts.clone()
                 far[0, 0] = torch.tensor(hi) + torch.tensor([0.5, 0.5, -0.5])
-                cover_all = all(w == (0, R, 0, R) for w in windows)
-                assert up.windows_contain(bounds, far, R, radius) == cover_all
-            # sizes only grow
+                cover_all = all(bool(w["mask"].all()) for w in plan)
+                assert up.windows_contain(plan, far, R, radius) == cover_all
+            # a margin activates the neighbouring tiles too; crop sizes only grow
             up._window_sizes = [[0, 0] for _ in range(3)]
-            w_small, _ = up.plan_windows(torch.zeros(1, 4, 3), R, radius)
-            w_big, _ = up.plan_windows(torch.tensor([[[-0.9, -0.9, -0.9], [0.9, 0.9, 0.9]]]), R, radius)
-            w_again, _ = up.plan_windows(torch.zeros(1, 4, 3), R, radius)
-            size = lambda w: [(y1 - y0, x1 - x0) for y0, y1, x0, x1 in w]
-            assert size(w_again) == size(w_big) and size(w_small) != size(w_big)
+            one = torch.zeros(1, 1, 3) + 0.01
+            tight = up.plan_windows(one, R, radius)
+            wide = up.plan_windows(one, R, radius, margin=1.0)
+            assert all(int(w["mask"].sum()) >= int(t["mask"].sum()) for w, t in zip(wide, tight))
+            assert any(int(w["mask"].sum()) > int(t["mask"].sum()) for w, t in zip(wide, tight))
+            again = up.plan_windows(one, R, radius)
+            size = lambda pl: [(w["crop"][1] - w["crop"][0], w["crop"][3] - w["crop"][2]) for w in pl]
+            assert size(again) == size(wide)

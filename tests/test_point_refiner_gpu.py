@@ -243,7 +243,7 @@ def test_windowed_upsampler_with_refiner_and_fallback():
 
     pcfg = dict(stride=(2,), enc_depths=(1, 1), enc_channels=(32, 64), enc_num_head=(2, 4), enc_patch_size=(256, 256),
                 dec_depths=(1,), dec_channels=(32,), dec_num_head=(2,), dec_patch_size=(256,))
-    base = dict(image_size=(64, 64), subdivide_steps=0, triplane_feature_dim=16, triplane_resolution=16,
+    base = dict(image_size=(64, 64), subdivide_steps=0, triplane_feature_dim=16, triplane_resolution=32,
                 predict_smplx_params=False, no_point_refiner=False, num_gaussians=1200, upsample_triplane=True,
                 num_upsample_blocks=2, radius=2.8, **pcfg)   # radius 2.8: the body fills a quarter of the planes
     r_win = init_random_heads(Renderer(RendererConfig(upsample_windows=True, **base)).eval(), std=0.05)
@@ -266,7 +266,7 @@ def test_windowed_upsampler_with_refiner_and_fallback():
             _, g_full = r_full(tokens, cam, dummy, smpl)
         assert bool(calls) == expect_fallback, (shift, calls)
         if not expect_fallback:
-            w = r_win.triplane_upsampler._window_sizes
-            assert all(s < 16 for pair in w for s in pair), w     # really cropped
+            plan = r_win._window_bounds
+            assert all(w["tiles"] for w in plan) and all(int(w["mask"].sum()) <= 32 for w in plan)  # really tiled: <= half
         for k in ("xyz", "scale", "rot", "opacity", "color"):
             assert (g_win[k] - g_full[k]).abs().max() <= 2e-5, (shift, k)
