@@ -307,7 +307,7 @@ class Renderer(nn.Module):
             if getattr(self.cfg, "upsample_windows", True):
                 # only the texels the body's points can sample are upsampled (TriplaneUpsampler, "windowed evaluation")
                 refiner = hasattr(self, "point_encoder")
-                margin = float(getattr(self.cfg, "upsample_window_margin", 0.1)) if refiner else 0.0
+                margin = float(getattr(self.cfg, "upsample_window_margin", 0.05)) if refiner else 0.0
                 plan = up.plan_windows(self.get_smpl_vertices(smpl_params), R, self.cfg.radius, margin)
                 tokens = up.forward_tokens_windowed(coarse, R, plan)
                 self._window_bounds = plan if refiner else None  # refined points are checked against it
@@ -371,11 +371,7 @@ class TriplaneUpsampler(nn.Module):
     def forward(self, triplanes):
         """[B,3,C,H,W] -> [B,3,C,2^n H,2^n W]"""
         B, P, C, H, W = triplanes.shape
-        cur = triplanes.reshape(B * P, C, H, W)
-        skip = cur
-        for block, skip_conn in zip(self.upsample_blocks, self.skip_connections):
-            skip = skip_conn(skip)
-            cur = block(cur) + skip
+        cur, _ = self._run(triplanes.reshape(B * P, C, H, W))
         return cur.reshape(B, P, C, cur.shape[-2], cur.shape[-1])
 
     def forward_tokens(self, tokens, resolution):
@@ -393,13 +389,13 @@ class TriplaneUpsampler(nn.Module):
     #     of [nearest x2, three 3x3 convolutions] that error has travelled d_k = 2 d_(k-1) + 3 = 3 (2^k - 1) texels;
     #   * the last block (three quarters of the flops) runs on the ACTIVE TILES only: output tiles of 4 x 4 input
     #     cells (64 x 64 texels for n = 4) that contain a bilinear tap of some point, each cut out of the level-(n-1)
-    #     activation with a 2-texel halo (the block's own reach is 3 output texels), batched through the library's
-    #     convolutions and written into their place of the full-resolution slab.
+    #     activation with a 2-texel halo (the block's own reach is 3 output texels), laid out as a mosaic image, run
+    #     through the library's convolutions and written into their place of the full-resolution slab.
     # Texels inside active tiles are the full computation's values (identical operands, possibly another library
     # kernel: rounding-level differences); the rest of the slab keeps whatever it held and is never sampled.  Where a
-    # crop coincides with the plane's own border the zero padding IS the reference's; a tile whose halo would cross
-    # the plane's border makes its plane take the last block on the whole crop instead.  Crop sizes and tile-batch
-    # sizes only grow (steps of 4 cells / 8 tiles), so the library sees few distinct convolution shapes.
+    # crop coincides with the plane's own border the zero padding IS the reference's; the halo of a tile at the plane's
+    # border lies outside the plane and is zeroed before every convolution, as zero padding would.  Crop sizes and tile-batch
+    # sizes only grow (steps of 4 cells / 4 tiles), so the library sees few distinct convolution shapes.
     PLANE_AXES = ((0, 1), (0, 2), (1, 2))  # (width, height) coordinate of plane p (renderer.py:300-310)
     TILE_CELLS = 4
 
@@ -415,43 +411,45 @@ class TriplaneUpsampler(nn.Module):
         return first.clamp(0, r_out - 1).long(), (first + 1).clamp(0, r_out - 1).long(), r_out
 
     def _active_tiles(self, points, resolution, radius, margin):
-        """bool [3, g, g] (plane, tile row, tile column), g = resolution / TILE_CELLS: tiles holding a tap of a point
-        (or of the point displaced by up to `margin` metres along every axis)."""
+        """bool [F, 3, g, g] (frame, plane, tile row, tile column), g = resolution / TILE_CELLS: tiles holding a tap of a
+        point of that frame (or of the point displaced by up to `margin` metres along every axis)."""
         g = resolution // self.TILE_CELLS
         tile = self.TILE_CELLS * 2 ** len(self.upsample_blocks)
+        F, N, _ = points.shape
         flat = points.reshape(-1, 3)
         lo, _, _ = self._taps(flat - margin, resolution, radius)
         _, hi, _ = self._taps(flat + margin, resolution, radius)
-        lo, hi = lo // tile, hi // tile                     # [M,3] tile index per coordinate
-        mask = torch.zeros(3, g, g, dtype=torch.bool, device=points.device)
+        lo, hi = lo // tile, hi // tile                     # [F N, 3] tile index per coordinate
+        frame = torch.arange(F, device=points.device).repeat_interleave(N)
+        mask = torch.zeros(F, 3, g, g, dtype=torch.bool, device=points.device)
         span = int((hi - lo).max()) if flat.shape[0] else 0   # (host sync) usually 1: a tap pair straddles a tile edge
         for p, (aw, ah) in enumerate(self.PLANE_AXES):
             for dy in range(span + 1):
                 for dx in range(span + 1):
-                    mask[p, torch.minimum(lo[:, ah] + dy, hi[:, ah]), torch.minimum(lo[:, aw] + dx, hi[:, aw])] = True
+                    mask[frame, p, torch.minimum(lo[:, ah] + dy, hi[:, ah]), torch.minimum(lo[:, aw] + dx, hi[:, aw])] = True
         return mask
 
     def plan_windows(self, points, resolution, radius, margin=0.0):
-        """points [F,N,3] -> plan: per plane {crop (y0,y1,x0,x1) in input cells, tiles [(ty,tx)...] or None (last block
-        on the whole crop), mask}.  Host syncs: the tile mask."""
+        """points [F,N,3] -> plan: per plane {crop (y0,y1,x0,x1) in input cells (common to the frames), tiles int64
+        [K,3] (frame, tile row, tile column; None = whole planes: resolution not a multiple of TILE_CELLS, or a diverged
+        pose), mask bool [F,g,g]}.  Host sync: the tile mask."""
         n = len(self.upsample_blocks)
         R = resolution
         if not hasattr(self, "_window_sizes"):
             self._window_sizes = [[0, 0] for _ in range(3)]
-        finite = bool(torch.isfinite(points).all())
-        if R % self.TILE_CELLS or not finite:  # no tiling / a diverged pose: whole planes
+        if R % self.TILE_CELLS or not bool(torch.isfinite(points).all()):  # no tiling / a diverged pose: whole planes
             return [dict(crop=(0, R, 0, R), tiles=None, mask=None) for _ in range(3)]
         mask = self._active_tiles(points, R, radius, margin).cpu()
         halo_cells = 3 if n >= 2 else 2
-        s_in = 2 ** (n - 1)                 # texels per input cell at the last block's input
         plan = []
         for p in range(3):
-            ys, xs = torch.nonzero(mask[p], as_tuple=True)
-            if ys.numel() == 0:
-                plan.append(dict(crop=(0, self.TILE_CELLS, 0, self.TILE_CELLS), tiles=[], mask=mask[p]))
+            tiles = torch.nonzero(mask[:, p])                          # [K,3]: frame, ty, tx
+            if tiles.shape[0] == 0:
+                plan.append(dict(crop=(0, self.TILE_CELLS, 0, self.TILE_CELLS), tiles=tiles, mask=mask[:, p]))
                 continue
             spans = []
-            for slot, idx in ((0, ys), (1, xs)):
+            for slot in (0, 1):
+                idx = tiles[:, 1 + slot]
                 c0 = max(0, int(idx.min()) * self.TILE_CELLS - halo_cells)
                 c1 = min(R, (int(idx.max()) + 1) * self.TILE_CELLS + halo_cells)
                 size = min(R, max(self._window_sizes[p][slot], -(-(c1 - c0) // 4) * 4))
@@ -459,11 +457,7 @@ class TriplaneUpsampler(nn.Module):
                 start = min(max(0, c0 - (size - (c1 - c0)) // 2), R - size)
                 spans.append((start, start + size))
             (y0, y1), (x0, x1) = spans
-            tiles = list(zip(ys.tolist(), xs.tolist()))
-            t_in = self.TILE_CELLS * s_in
-            inside = all(ty * t_in - 2 >= 0 and (ty + 1) * t_in + 2 <= R * s_in and tx * t_in - 2 >= 0
-                         and (tx + 1) * t_in + 2 <= R * s_in for ty, tx in tiles)
-            plan.append(dict(crop=(y0, y1, x0, x1), tiles=tiles if inside else None, mask=mask[p]))
+            plan.append(dict(crop=(y0, y1, x0, x1), tiles=tiles, mask=mask[:, p]))
         return plan
 
     def windows_contain(self, plan, points, resolution, radius):
@@ -471,16 +465,41 @@ class TriplaneUpsampler(nn.Module):
         if all(w["mask"] is None for w in plan):
             return True
         need = self._active_tiles(points, resolution, radius, 0.0).cpu()
-        return all(w["mask"] is None or not bool((need[p] & ~w["mask"]).any()) for p, w in enumerate(plan))
+        return all(w["mask"] is None or not bool((need[:, p] & ~w["mask"]).any()) for p, w in enumerate(plan))
 
-    def _run(self, cur, first=0, last=None, skip=None):
-        """Blocks first .. last-1 on [B,C,h,w]; returns (activation, skip chain) at the output resolution."""
-        skip = cur if skip is None else skip
+    MAX_ACTIVATION_BYTES = 2 ** 31  # the library's convolutions corrupt batch items that lie beyond a 4 GiB offset
+    # (tools/upsampler_debug.py: 18 planes x 256 x 512^2 fp32 = 4.8 GB, i.e. the reference's own 6-frame window, come
+    # back wrong for the last two planes); every call therefore keeps its largest activation below 2 GiB
+
+    def _run(self, cur, first=0, last=None):
+        """Blocks first .. last-1 on [B,C,h,w]; returns (activation, skip chain) at the output resolution.  The batch
+        is processed in chunks small enough for MAX_ACTIVATION_BYTES."""
         blocks = list(zip(self.upsample_blocks, self.skip_connections))[first:last]
-        for block, skip_conn in blocks:
-            skip = skip_conn(skip)
-            cur = block(cur) + skip
-        return cur, skip
+        B, C, h, w = cur.shape
+        per_item = C * h * w * 4 ** len(blocks) * cur.element_size()
+        step = max(1, self.MAX_ACTIVATION_BYTES // max(per_item, 1))
+        outs, skips = [], []
+        for s in range(0, B, step):
+            x = skip = cur[s:s + step]
+            for block, skip_conn in blocks:
+                skip = skip_conn(skip)
+                x = block(x) + skip
+            outs.append(x)
+            skips.append(skip)
+        return (outs[0], skips[0]) if len(outs) == 1 else (torch.cat(outs), torch.cat(skips))
+
+    @staticmethod
+    def _last_block(block, image, valid=None):
+        """UpsampleBlock.forward; with `valid` [1,1,2h,2w] the inputs of the 2nd and 3rd convolution are zeroed where
+        the mosaic holds positions outside a plane (zero padding is what the reference's convolutions see there)."""
+        if valid is None:
+            return block(image)
+        up, conv, relu, res = block.upsample
+        x = relu(conv(up(image)))
+        b = res.block
+        r = b[2](b[1](b[0](x)) * valid)
+        r = b[5](b[4](b[3](r)) * valid)
+        return res.skip(x) + r
 
     def forward_tokens_windowed(self, tokens, resolution, plan, out=None):
         """Token slab [F,C,3 R^2] + plan_windows()' plan -> full-resolution slab [F,C,3 (2^n R)^2] whose texels inside
@@ -499,31 +518,66 @@ class TriplaneUpsampler(nn.Module):
         ov = out.view(F, C, 3, r_out, r_out)
         if not hasattr(self, "_tile_batch"):
             self._tile_batch = [0, 0, 0]
+        t_in, t_out, g = self.TILE_CELLS * s_in, self.TILE_CELLS * scale, resolution // self.TILE_CELLS
+        P, cols = t_in + 4, 8
         for p, w in enumerate(plan):
             y0, y1, x0, x1 = w["crop"]
-            if w["tiles"] is not None and not w["tiles"]:
+            tiles = w["tiles"]
+            if tiles is not None and tiles.shape[0] == 0:
                 continue  # no point samples this plane
             crop = planes[:, :, p, y0:y1, x0:x1].contiguous()
-            if w["tiles"] is None:
+            if tiles is None:
                 up, _ = self._run(crop)
                 ov[:, :, p, y0 * scale:y1 * scale, x0 * scale:x1 * scale] = up
                 continue
-            act, skip = self._run(crop, 0, n - 1)           # level n-1: [F,C,(y1-y0) s_in, (x1-x0) s_in]
-            t_in, t_out = self.TILE_CELLS * s_in, self.TILE_CELLS * scale
-            tiles = w["tiles"]
-            count = max(self._tile_batch[p], -(-len(tiles) // 8) * 8)
-            self._tile_batch[p] = count
-            xb = act.new_zeros(count, F, C, t_in + 4, t_in + 4)
-            sb = act.new_zeros(count, F, C, t_in, t_in)
-            for i, (ty, tx) in enumerate(tiles):
-                r0, c0 = ty * t_in - y0 * s_in, tx * t_in - x0 * s_in
-                xb[i] = act[:, :, r0 - 2:r0 + t_in + 2, c0 - 2:c0 + t_in + 2]
-                sb[i] = skip[:, :, r0:r0 + t_in, c0:c0 + t_in]
+            act, skip = self._run(crop, 0, n - 1)           # level n-1: [F,C,(y1-y0) s_in,(x1-x0) s_in]
+            # tile (ty, tx) with its 2-texel halo starts at row ty t_in - y0 s_in of the activation padded by 2 (the
+            # padding is only ever read where the crop ends at the plane's own border: zeros, as the reference pads)
+            tiles = tiles.to(tokens.device)
+            f_idx, ty, tx = tiles[:, 0], tiles[:, 1], tiles[:, 2]
+            K = int(tiles.shape[0])
+
+            def tile_windows(x, size):
+                ay, ax = -(-(y0 * s_in) // t_in), -(-(x0 * s_in) // t_in)
+                wv = x[:, :, ay * t_in - y0 * s_in:].unfold(2, size, t_in).permute(0, 1, 2, 4, 3)   # [F,C,ky,size,W]
+                wv = wv[..., ax * t_in - x0 * s_in:].unfold(4, size, t_in)                           # [F,C,ky,size,kx,size]
+                return wv[f_idx, :, ty - ay, :, tx - ax, :]                                          # [K,C,size,size]
+
+            cells = tile_windows(torch.nn.functional.pad(act, (2, 2, 2, 2)), P)
+            skips = tile_windows(skip, t_in)
+            # positions of a cell that lie outside the plane (halo of a tile at the plane's border): the reference's
+            # convolutions read zeros there at EVERY layer, so they are zeroed again before the 2nd and 3rd convolution
+            extent = resolution * scale
+            pos = torch.arange(2 * P, device=tokens.device) - 4
+            vy = ((ty * t_out)[:, None] + pos >= 0) & ((ty * t_out)[:, None] + pos < extent)        # [K,2P]
+            vx = ((tx * t_out)[:, None] + pos >= 0) & ((tx * t_out)[:, None] + pos < extent)
+            border = not bool(vy.all() and vx.all())
+            valid = (vy[:, :, None] & vx[:, None, :]).to(act.dtype)[:, None] if border else None    # [K,1,2P,2P]
+            # ONE mosaic image of all (frame, tile) cells, `cols` cells wide: neighbouring cells only see each other
+            # inside the halos that are cut away
+            rows = max(self._tile_batch[p], -(-K // cols))
+            self._tile_batch[p] = rows
+            max_rows = max(1, self.MAX_ACTIVATION_BYTES // (C * 4 * P * P * cols * 4))  # per mosaic image
             block, skip_conn = self.upsample_blocks[n - 1], self.skip_connections[n - 1]
-            res = block(xb.view(count * F, C, t_in + 4, t_in + 4))[:, :, 4:-4, 4:-4]
-            res = (res + skip_conn(sb.view(count * F, C, t_in, t_in))).view(count, F, C, t_out, t_out)
-            for i, (ty, tx) in enumerate(tiles):
-                ov[:, :, p, ty * t_out:(ty + 1) * t_out, tx * t_out:(tx + 1) * t_out] = res[i]
+            vals = act.new_empty(K, C, t_out, t_out)
+            for r0 in range(0, rows, max_rows):
+                nr = min(max_rows, rows - r0)
+                k0, k1 = r0 * cols, min(K, (r0 + nr) * cols)
+                if k0 >= K:
+                    break
+                mosaic = act.new_zeros(nr * cols, C, P, P)
+                mosaic[:k1 - k0] = cells[k0:k1]
+                image = mosaic.view(nr, cols, C, P, P).permute(2, 0, 3, 1, 4).reshape(1, C, nr * P, cols * P)
+                m_img = None
+                if border:
+                    m = act.new_ones(nr * cols, 1, 2 * P, 2 * P)
+                    m[:k1 - k0] = valid[k0:k1]
+                    m_img = m.view(nr, cols, 1, 2 * P, 2 * P).permute(2, 0, 3, 1, 4).reshape(1, 1, nr * 2 * P, cols * 2 * P)
+                res = self._last_block(block, image, m_img)
+                res = res.view(C, nr, 2 * P, cols, 2 * P).permute(1, 3, 0, 2, 4).reshape(nr * cols, C, 2 * P, 2 * P)
+                vals[k0:k1] = res[:k1 - k0, :, 4:4 + t_out, 4:4 + t_out]
+            vals += skip_conn(skips)
+            ov.view(F, C, 3, g, t_out, g, t_out)[f_idx, :, p, ty, :, tx, :] = vals
         return out
 
 

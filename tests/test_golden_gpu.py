@@ -201,3 +201,22 @@ def test_smplx_decoder_on_the_device_matches_the_oracle_directly():
     assert (batch_rodrigues(got_aa) - R).abs().max() <= 2e-4  # and both encode the rotation they were built from
     small = angles.repeat(axes.shape[0]) < 3.05
     assert (got_aa[small] - want_aa[small]).abs().max() <= 2e-5
+
+
+def test_upsampler_window_of_six_frames_stays_below_the_4_gib_library_limit():
+    """The reference's own window (6 frames x 3 planes x 256 x 512^2 fp32 = 4.8 GB per activation) through the library
+    convolutions in one batch comes back wrong for the planes beyond a 4 GiB offset (tools/upsampler_debug.py);
+    TriplaneUpsampler chunks its batches, so the whole window equals the same planes run three at a time."""
+    from types import SimpleNamespace
+
+    from audio_motion_avatar_amd.renderer import TriplaneUpsampler
+
+    torch.manual_seed(0)
+    up = TriplaneUpsampler(SimpleNamespace(triplane_feature_dim=256, num_upsample_blocks=4)).eval().cuda()
+    x = torch.randn(6, 3, 256, 32, 32, device="cuda")
+    with torch.no_grad():
+        whole = up(x)
+        assert whole.shape == (6, 3, 256, 512, 512)
+        for f in (0, 5):
+            part = up(x[f:f + 1])
+            assert (whole[f:f + 1] - part).abs().max() <= 1e-4, f

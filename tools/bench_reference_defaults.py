@@ -11,6 +11,9 @@ import time
 
 import torch
 
+if os.environ.get("AMAV_CONV_BENCHMARK"):
+    torch.backends.cudnn.benchmark = True  # MIOpen find mode: search the convolution kernels per shape
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from audio_motion_avatar_amd.config import RendererConfig  # noqa: E402
 from audio_motion_avatar_amd.renderer import Renderer  # noqa: E402
@@ -18,6 +21,8 @@ from audio_motion_avatar_amd.synthetic import init_random_heads, make_render_inp
 
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 for label, kw in (("upsampler + refiner, 30k", dict(upsample_triplane=True, no_point_refiner=False, subdivide_steps=2)),
+                  ("same, margin 0", dict(upsample_triplane=True, no_point_refiner=False, subdivide_steps=2, upsample_window_margin=0.0)),
+                  ("upsampler only, 30k", dict(upsample_triplane=True, subdivide_steps=2)),
                   ("refiner only, 30k", dict(no_point_refiner=False, subdivide_steps=2)),
                   ("neither, 30k", dict(subdivide_steps=2)), ("neither, 10k (BASELINE)", dict(subdivide_steps=0))):
     cfg = RendererConfig(image_size=(512, 512), predict_smplx_params=False, device="cuda", **kw)
@@ -37,7 +42,9 @@ for label, kw in (("upsampler + refiner, 30k", dict(upsample_triplane=True, no_p
             images, _ = r(tokens, cam, dummy, smpl)
         torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 3 / F
-    print(f"{label:28s} {dt * 1e3:8.2f} ms per frame ({F} frames per call), coverage {float((images < 0.999).any(-1).float().mean()):.3f}",
-          flush=True)
+    plan = getattr(r, "_window_bounds", None)
+    tiles = [round(int(w["mask"].sum()) / F, 1) for w in plan] if plan else None
+    print(f"{label:28s} {dt * 1e3:8.2f} ms per frame ({F} frames per call), coverage {float((images < 0.999).any(-1).float().mean()):.3f}"
+          f", active tiles of 64 per plane {tiles}", flush=True)
     del r
     torch.cuda.empty_cache()

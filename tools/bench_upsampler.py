@@ -10,6 +10,9 @@ import time
 
 import torch
 
+if os.environ.get("AMAV_CONV_BENCHMARK"):
+    torch.backends.cudnn.benchmark = True  # MIOpen find mode: search the convolution kernels per shape
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from audio_motion_avatar_amd.config import RendererConfig  # noqa: E402
 from audio_motion_avatar_amd.renderer import Renderer  # noqa: E402
@@ -59,11 +62,11 @@ with torch.no_grad():
     dw = (time.perf_counter() - t0) / reps / F
     R = cfg.triplane_resolution
     cells = sum((w["crop"][1] - w["crop"][0]) * (w["crop"][3] - w["crop"][2]) for w in plan) / (3 * R * R)
-    tiles = sum(int(w["mask"].sum()) for w in plan) / (3 * (R // 4) ** 2)
+    tiles = sum(int(w["mask"].sum()) for w in plan) / (3 * F * (R // 4) ** 2)
     r_out, t = R * 16, 64
     fv, wv = out.view(F, -1, 3, r_out, r_out), win.view(F, -1, 3, r_out, r_out)
-    err = max(float((fv[:, :, p, ty * t:(ty + 1) * t, tx * t:(tx + 1) * t] - wv[:, :, p, ty * t:(ty + 1) * t, tx * t:(tx + 1) * t]).abs().max())
-              for p, w in enumerate(plan) for ty, tx in zip(*torch.nonzero(w["mask"], as_tuple=True)))
+    err = max(float((fv[f, :, p, ty * t:(ty + 1) * t, tx * t:(tx + 1) * t] - wv[f, :, p, ty * t:(ty + 1) * t, tx * t:(tx + 1) * t]).abs().max())
+              for p, w in enumerate(plan) for f, ty, tx in torch.nonzero(w["mask"]).tolist())
 print(f"windowed: {dw * 1e3:.1f} ms per frame; crops {[w['crop'] for w in plan]} = {cells * 100:.0f} % of the cells for blocks 1-3, "
       f"{tiles * 100:.0f} % of the tiles for block 4 (tiled: {[w['tiles'] is not None for w in plan]}); "
       f"max |full - windowed| inside the active tiles {err:.2e}")
