@@ -124,6 +124,9 @@ def main(argv=None):
     ap.add_argument("--frames", type=int, default=48)
     ap.add_argument("--image-size", type=int, nargs=2, default=(512, 512), metavar=("H", "W"))
     ap.add_argument("--interleave", action="store_true", help="the demo's even / odd chains zipped (main2.py:160-311)")
+    ap.add_argument("--reference-renderer", action="store_true",
+                    help="the reference's default renderer.yaml: triplane upsampler x16, PTv3 point refiner, 30 000 Gaussians "
+                         "(what a released checkpoint was trained with); default is BASELINE's 10 000-Gaussian renderer")
     ap.add_argument("--fps", type=float, default=24.0)
     ap.add_argument("--out", default="demo.rgb", help=".rgb (raw frames + .json), .mp4 / .mkv / .mov (needs ffmpeg) or - for stdout")
     ap.add_argument("--device", default="cuda")
@@ -131,7 +134,8 @@ def main(argv=None):
     args = ap.parse_args(argv)
 
     H, W = args.image_size
-    rcfg = RendererConfig(image_size=(H, W), device=args.device, smplx_model_path=args.smplx_model_path)
+    extra = dict(upsample_triplane=True, no_point_refiner=False, subdivide_steps=2) if args.reference_renderer else {}
+    rcfg = RendererConfig(image_size=(H, W), device=args.device, smplx_model_path=args.smplx_model_path, **extra)
     cfg = ModelConfig(renderer=rcfg)
     torch.manual_seed(args.seed)
     model = AudioDrivenAvatar(cfg)
