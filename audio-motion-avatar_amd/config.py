@@ -31,6 +31,7 @@ class RendererConfig:
     upsample_triplane: bool = False   # reference default true: SURVEY 8(f) next-row
     num_upsample_blocks: int = 4
     upsample_windows: bool = True     # upsample only the plane regions the body's points can sample (renderer.py, TriplaneUpsampler)
+    upsample_frames_per_pass: int = 8    # Renderer.forward splits longer calls (upsampled planes: 805 MB per frame)
     upsample_window_margin: float = 0.05  # metres kept free around the points for the refiner's offsets (checked; falls back)
     densify_smplx_verts: bool = True
     subdivide_steps: int = 0          # 0 -> 10 000 sampled vertices (BASELINE), reference default 2 -> 30 000

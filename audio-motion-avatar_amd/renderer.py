@@ -284,6 +284,24 @@ class Renderer(nn.Module):
         if smpl_tokens is None:
             raise AmavError("Renderer.forward needs smpl_tokens (the reference dereferences it too, renderer.py:84)")
         B, T = smpl_tokens.shape[:2]
+        limit = int(getattr(self.cfg, "upsample_frames_per_pass", 8))
+        if getattr(self.cfg, "upsample_triplane", False) and B * T > limit:
+            # upsampled planes are 805 MB per frame at the reference defaults: longer calls go through in passes of
+            # `limit` frames (the reference itself renders six-frame windows); frames are independent
+            flat = lambda v: v.reshape(1, B * T, *v.shape[2:])
+            parts = []
+            for s0 in range(0, B * T, limit):
+                sl = slice(s0, s0 + limit)
+                parts.append(self.forward(flat(triplane_features)[:, sl], {k: flat(v)[:, sl] for k, v in cam_params.items()},
+                                          flat(smpl_tokens)[:, sl], None if smpl_params_gt is None else
+                                          {k: flat(v)[:, sl] for k, v in smpl_params_gt.items()}))
+            images = torch.cat([o[0] for o in parts], dim=1)
+            images = images.reshape(B, T, *images.shape[2:])
+            gaussians = {k: torch.cat([o[1][k] for o in parts], dim=0) for k in parts[0][1]}
+            if self.cfg.predict_smplx_params:
+                pred = {k: torch.cat([o[2][k] for o in parts], dim=1) for k in parts[0][2]}
+                return images, gaussians, {k: v.reshape(B, T, *v.shape[2:]) for k, v in pred.items()}
+            return images, gaussians
         tokens = triplane_features.reshape(B * T, triplane_features.shape[2], triplane_features.shape[3]).float()
 
         pred_smpl_params = None

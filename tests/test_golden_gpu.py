@@ -146,6 +146,35 @@ def test_triplane_upsampler_path_matches_oracle():
     assert images.shape == (1, F_, 64, 64, 3)
 
 
+def test_upsampler_path_splits_long_calls():
+    """Renderer.forward with upsample_triplane=True and more frames than cfg.upsample_frames_per_pass == the same frames
+    in one pass (frames are independent; the split only bounds the 805 MB-per-frame slab)."""
+    from audio_motion_avatar_amd.config import RendererConfig
+    from audio_motion_avatar_amd.renderer import Renderer
+    from audio_motion_avatar_amd.smplx_decoder import SMPLXDecoder
+    from audio_motion_avatar_amd.synthetic import init_random_heads, make_render_inputs
+
+    base = dict(image_size=(48, 48), subdivide_steps=0, triplane_feature_dim=16, triplane_resolution=8,
+                smpl_token_dim=16, smpl_token_len=10, upsample_triplane=True, num_upsample_blocks=2, num_gaussians=800)
+    one = RendererConfig(upsample_frames_per_pass=64, **base)
+    r1 = init_random_heads(Renderer(one, smpl_decoder=SMPLXDecoder(one)).eval(), std=0.05)
+    two = RendererConfig(upsample_frames_per_pass=2, **base)
+    r2 = Renderer(two, smpl_decoder=SMPLXDecoder(two)).eval()
+    r2.load_state_dict(r1.state_dict())
+    B, T = 1, 5
+    tokens, _, cam = make_render_inputs(T, one, seed=5, batch=B)
+    smpl_tokens = torch.randn(B, T, 16, 10, device="cuda") * 0.3
+    with torch.no_grad():
+        i1, g1, p1 = r1(tokens, cam, smpl_tokens)
+        i2, g2, p2 = r2(tokens, cam, smpl_tokens)
+    assert i2.shape == i1.shape == (B, T, 48, 48, 3)
+    assert (i1 - i2).abs().max() <= 1e-5
+    for k in g1:
+        assert g2[k].shape == g1[k].shape and (g1[k] - g2[k]).abs().max() <= 1e-5, k
+    for k in p1:
+        assert p2[k].shape == p1[k].shape and (p1[k] - p2[k]).abs().max() <= 1e-6, k
+
+
 def test_smplx_decoder_on_the_device_matches_the_oracle_directly():
     """A4 on the GPU, directly: the device SMPLXDecoder's parameters against
     oracle.smplx_decoder_forward at the reference size (256 x 80 tokens), and the rot6d -> axis-angle conversion at
