@@ -285,6 +285,52 @@ __global__ __launch_bounds__(256) void sample_features_kernel(int N, int C, int 
     }
 }
 
+// The same for C % 64 == 0 (the point refiner's first sampling, 768 channels per point): a block is 64 points x 64
+// channels of one plane.  READ phase: lanes run along the POINTS, one channel image at a time, so a wave's 256 taps
+// fall into one 4 KB channel image (R = 32) instead of 64 images 12 KB apart; the 64 x 64 results go through LDS and
+// the WRITE phase runs lanes along the channels (256-byte rows of the [F, N, 3C] output).  Same arithmetic per
+// (point, channel) as the kernel above: bit-identical results.
+__global__ __launch_bounds__(256) void sample_features_tiled_kernel(int N, int C, int R, const float *__restrict__ planes,
+                                                                    long long frame_stride, long long plane_stride,
+                                                                    long long chan_stride,
+                                                                    const float *__restrict__ points, float radius,
+                                                                    float *__restrict__ out) {
+    __shared__ float tile[64 * 65];  // [channel][point]
+    const int f = blockIdx.z, oc0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int plane = oc0 / C, c0 = oc0 - plane * C;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = min(n0 + lane, N - 1);
+    const float *pp = points + ((size_t)f * N + n) * 3;
+    const float u0 = fminf(fmaxf(pp[0] / radius, -1.0f), 1.0f);
+    const float u1 = fminf(fmaxf(pp[1] / radius, -1.0f), 1.0f);
+    const float u2 = fminf(fmaxf(pp[2] / radius, -1.0f), 1.0f);
+    const Taps t = make_taps(plane == 2 ? u1 : u0, plane == 0 ? u1 : u2, R);
+    int off[4];
+    float wt[4];
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            const int ix = t.ix0 + dx, iy = t.iy0 + dy;
+            const bool in = ix >= 0 && ix < R && iy >= 0 && iy < R;
+            off[2 * dy + dx] = in ? iy * R + ix : -1;
+            wt[2 * dy + dx] = (dx ? t.wx1 : t.wx0) * (dy ? t.wy1 : t.wy0);
+        }
+    const float *pl = planes + (size_t)f * frame_stride + (size_t)plane * plane_stride + (size_t)c0 * chan_stride;
+    for (int k = wave; k < 64; k += 4) {
+        const float *img = pl + (size_t)k * chan_stride;
+        float acc = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (off[q] >= 0) acc += img[off[q]] * wt[q];
+        tile[k * 65 + lane] = acc;
+    }
+    __syncthreads();
+    for (int p = wave; p < 64; p += 4) {
+        if (n0 + p < N) out[((size_t)f * N + n0 + p) * 3 * C + oc0 + lane] = tile[lane * 65 + p];
+    }
+}
+
 }  // namespace triplane
 }  // namespace amav
 
@@ -361,9 +407,15 @@ extern "C" int amav_triplane_sample_features(int F, int N, int C, int R, const f
     AMAV_REQUIRE(F <= 65535, "amav_triplane_sample_features: F=%d exceeds grid.y", F);
     AMAV_REQUIRE(planes && points && out, "amav_triplane_sample_features: NULL pointer");
     AMAV_REQUIRE(radius > 0.0f, "amav_triplane_sample_features: radius must be positive");
-    const dim3 grid(N, F);
-    sample_features_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream_)>>>(N, C, R, planes, frame_stride,
-                                                                               plane_stride, chan_stride, points,
-                                                                               radius, out);
+    if (C % 64 == 0 && 3 * C / 64 <= 65535) {
+        const dim3 grid((unsigned)((N + 63) / 64), (unsigned)(3 * C / 64), (unsigned)F);
+        sample_features_tiled_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream_)>>>(
+            N, C, R, planes, frame_stride, plane_stride, chan_stride, points, radius, out);
+    } else {
+        const dim3 grid(N, F);
+        sample_features_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream_)>>>(N, C, R, planes, frame_stride,
+                                                                                   plane_stride, chan_stride, points,
+                                                                                   radius, out);
+    }
     return check_launch("amav_triplane_sample_features");
 }

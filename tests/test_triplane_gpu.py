@@ -91,6 +91,21 @@ def test_sample_features_matches_grid_sample(F, N, C, R):
     assert (got - ref).abs().max() <= 1e-5
 
 
+def test_sample_features_on_the_token_layout_matches_grid_sample():
+    """The refiner samples the [F, C, 3 R^2] token slab in place (a permuted view, channel stride 3 R^2), 64-channel
+    tiles, a ragged last point tile, points outside the radius."""
+    from audio_motion_avatar_amd import ops
+    from oracle import triplane as orc
+
+    F, N, C, R = 3, 130, 128, 16
+    tokens, points, _, _ = make_case(78, F, N, C, R)
+    points[0, :5] *= 4.0
+    ref = orc.sample_from_triplane(orc.tokens_to_planes(tokens[None], R), points, 1.4)
+    view = tokens.cuda().view(F, C, 3, R, R).permute(0, 2, 1, 3, 4)
+    got = ops.triplane_sample_features(view, points.cuda(), 1.4).cpu()
+    assert (got - ref).abs().max() <= 1e-5
+
+
 def test_indexed_decode_equals_gather_then_decode_bitwise():
     """amav_triplane_sample_decode_indexed == amav_points_gather + amav_triplane_sample_decode, bit for bit."""
     from audio_motion_avatar_amd import ops
