@@ -21,7 +21,6 @@ side-car with width / height / fps) or any writable binary stream works everywhe
 """
 import argparse
 import json
-import os
 import shutil
 import subprocess
 import sys

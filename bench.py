@@ -632,8 +632,6 @@ def main():
     workspaces = [None] * max(1, min(args.chunks, F))  # filled by the first step, then reused
     gather = FrameAllGather(F, H, W, world, device, wire=args.wire, algorithm=args.exchange) if dist is not None else None
 
-    import audio_motion_avatar_amd.renderer as R
-
     stages = [None, None]  # the last step's intermediate tensors (parity check)
 
     def step():
