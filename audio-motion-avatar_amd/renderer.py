@@ -402,13 +402,14 @@ class TriplaneUpsampler(nn.Module):
     # ---- windowed evaluation -----------------------------------------------------------------------------------------
     # The upsampled planes are only ever SAMPLED, at the body's points: a few per cent of the 512^2 texels of each plane.
     # Convolutions are translation-equivariant, so only what the sample points can reach is computed, in two stages:
-    #   * blocks 1 .. n-1 (a quarter of the flops) run on ONE crop per plane: the bounding box (in input cells) of the
+    #   * blocks 1 .. n-2 (6 % of the flops) run on ONE crop per plane: the bounding box (in input cells) of the
     #     active tiles plus a 3-cell halo.  A crop border feeds zeros where the full plane has values; after k blocks
     #     of [nearest x2, three 3x3 convolutions] that error has travelled d_k = 2 d_(k-1) + 3 = 3 (2^k - 1) texels;
-    #   * the last block (three quarters of the flops) runs on the ACTIVE TILES only: output tiles of 4 x 4 input
-    #     cells (64 x 64 texels for n = 4) that contain a bilinear tap of some point, each cut out of the level-(n-1)
-    #     activation with a 2-texel halo (the block's own reach is 3 output texels), laid out as a mosaic image, run
-    #     through the library's convolutions and written into their place of the full-resolution slab.
+    #   * the last two blocks (94 % of the flops) run on the ACTIVE TILES only: output tiles of 4 x 4 input cells
+    #     (64 x 64 texels for n = 4) that contain a bilinear tap of some point.  Cells of 16 + 6 texels of the
+    #     level-(n-2) activation go through block n-1; the centre 32 + 4 texels of the result are the padded tiles of
+    #     block n (a block's reach is 3 output texels, 4 are cut away), whose centre 64 are written into their place of
+    #     the full-resolution slab.  Each stage runs as one mosaic image through the library's convolutions.
     # Texels inside active tiles are the full computation's values (identical operands, possibly another library
     # kernel: rounding-level differences); the rest of the slab keeps whatever it held and is never sampled.  Where a
     # crop coincides with the plane's own border the zero padding IS the reference's; the halo of a tile at the plane's
@@ -534,10 +535,8 @@ class TriplaneUpsampler(nn.Module):
             out = cached
         planes = tokens.view(F, C, 3, resolution, resolution)
         ov = out.view(F, C, 3, r_out, r_out)
-        if not hasattr(self, "_tile_batch"):
-            self._tile_batch = [0, 0, 0]
         t_in, t_out, g = self.TILE_CELLS * s_in, self.TILE_CELLS * scale, resolution // self.TILE_CELLS
-        P, cols = t_in + 4, 8
+        P = t_in + 4
         for p, w in enumerate(plan):
             y0, y1, x0, x1 = w["crop"]
             tiles = w["tiles"]
@@ -548,54 +547,86 @@ class TriplaneUpsampler(nn.Module):
                 up, _ = self._run(crop)
                 ov[:, :, p, y0 * scale:y1 * scale, x0 * scale:x1 * scale] = up
                 continue
-            act, skip = self._run(crop, 0, n - 1)           # level n-1: [F,C,(y1-y0) s_in,(x1-x0) s_in]
-            # tile (ty, tx) with its 2-texel halo starts at row ty t_in - y0 s_in of the activation padded by 2 (the
-            # padding is only ever read where the crop ends at the plane's own border: zeros, as the reference pads)
             tiles = tiles.to(tokens.device)
             f_idx, ty, tx = tiles[:, 0], tiles[:, 1], tiles[:, 2]
-            K = int(tiles.shape[0])
-
-            def tile_windows(x, size):
-                ay, ax = -(-(y0 * s_in) // t_in), -(-(x0 * s_in) // t_in)
-                wv = x[:, :, ay * t_in - y0 * s_in:].unfold(2, size, t_in).permute(0, 1, 2, 4, 3)   # [F,C,ky,size,W]
-                wv = wv[..., ax * t_in - x0 * s_in:].unfold(4, size, t_in)                           # [F,C,ky,size,kx,size]
-                return wv[f_idx, :, ty - ay, :, tx - ax, :]                                          # [K,C,size,size]
-
-            cells = tile_windows(torch.nn.functional.pad(act, (2, 2, 2, 2)), P)
-            skips = tile_windows(skip, t_in)
-            # positions of a cell that lie outside the plane (halo of a tile at the plane's border): the reference's
-            # convolutions read zeros there at EVERY layer, so they are zeroed again before the 2nd and 3rd convolution
             extent = resolution * scale
-            pos = torch.arange(2 * P, device=tokens.device) - 4
-            vy = ((ty * t_out)[:, None] + pos >= 0) & ((ty * t_out)[:, None] + pos < extent)        # [K,2P]
-            vx = ((tx * t_out)[:, None] + pos >= 0) & ((tx * t_out)[:, None] + pos < extent)
-            border = not bool(vy.all() and vx.all())
-            valid = (vy[:, :, None] & vx[:, None, :]).to(act.dtype)[:, None] if border else None    # [K,1,2P,2P]
-            # ONE mosaic image of all (frame, tile) cells, `cols` cells wide: neighbouring cells only see each other
-            # inside the halos that are cut away
-            rows = max(self._tile_batch[p], -(-K // cols))
-            self._tile_batch[p] = rows
-            max_rows = max(1, self.MAX_ACTIVATION_BYTES // (C * 4 * P * P * cols * 4))  # per mosaic image
-            block, skip_conn = self.upsample_blocks[n - 1], self.skip_connections[n - 1]
-            vals = act.new_empty(K, C, t_out, t_out)
-            for r0 in range(0, rows, max_rows):
-                nr = min(max_rows, rows - r0)
-                k0, k1 = r0 * cols, min(K, (r0 + nr) * cols)
-                if k0 >= K:
-                    break
-                mosaic = act.new_zeros(nr * cols, C, P, P)
-                mosaic[:k1 - k0] = cells[k0:k1]
-                image = mosaic.view(nr, cols, C, P, P).permute(2, 0, 3, 1, 4).reshape(1, C, nr * P, cols * P)
-                m_img = None
-                if border:
-                    m = act.new_ones(nr * cols, 1, 2 * P, 2 * P)
-                    m[:k1 - k0] = valid[k0:k1]
-                    m_img = m.view(nr, cols, 1, 2 * P, 2 * P).permute(2, 0, 3, 1, 4).reshape(1, 1, nr * 2 * P, cols * 2 * P)
-                res = self._last_block(block, image, m_img)
-                res = res.view(C, nr, 2 * P, cols, 2 * P).permute(1, 3, 0, 2, 4).reshape(nr * cols, C, 2 * P, 2 * P)
-                vals[k0:k1] = res[:k1 - k0, :, 4:4 + t_out, 4:4 + t_out]
-            vals += skip_conn(skips)
+
+            def tile_windows(x, level_scale, pad, size):
+                """[K,C,size,size]: for every active tile the window of `x` (level with `level_scale` texels per input
+                cell, cropped at (y0, x0), padded by `pad`) that starts `pad` texels before the tile."""
+                step = self.TILE_CELLS * level_scale
+                xp = torch.nn.functional.pad(x, (pad, pad, pad, pad)) if pad else x
+                ay, ax = -(-(y0 * level_scale) // step), -(-(x0 * level_scale) // step)
+                wv = xp[:, :, ay * step - y0 * level_scale:].unfold(2, size, step).permute(0, 1, 2, 4, 3)
+                wv = wv[..., ax * step - x0 * level_scale:].unfold(4, size, step)       # [F,C,ky,size,kx,size]
+                return wv[f_idx, :, ty - ay, :, tx - ax, :]
+
+            def validity(step, first, length):
+                """float [K,1,length,length] (or None when all ones): 1 where row ty step + first + j and the matching
+                column lie inside the plane at that level (plane size = extent / t_out * step)."""
+                size = extent // t_out * step
+                pos = torch.arange(length, device=tokens.device) + first
+                vy = ((ty * step)[:, None] + pos >= 0) & ((ty * step)[:, None] + pos < size)
+                vx = ((tx * step)[:, None] + pos >= 0) & ((tx * step)[:, None] + pos < size)
+                if bool(vy.all() and vx.all()):
+                    return None
+                return (vy[:, :, None] & vx[:, None, :]).to(tokens.dtype)[:, None]
+
+            chain = n >= 2 and bool(getattr(self.cfg, "upsample_tile_chain", True))
+            if chain:
+                # the LAST TWO blocks on the active tiles: cells of t2 + 6 texels at level n-2 -> block n-1 -> the centre
+                # t_in + 4 texels are exactly the padded tiles of block n (reach of one block: 3 <= the 4 cut away)
+                s2 = 2 ** (n - 2)
+                t2 = self.TILE_CELLS * s2
+                act2, skip2 = self._run(crop, 0, n - 2)
+                res = self._mosaic(self.upsample_blocks[n - 2], tile_windows(act2, s2, 3, t2 + 6),
+                                   validity(t_in, -6, 2 * (t2 + 6)), p, 0)[:, :, 4:-4, 4:-4]           # [K,C,P,P]
+                skip1 = self.skip_connections[n - 2](tile_windows(skip2, s2, 1, t2 + 2))                # [K,C,P,P]
+                cells = res + skip1
+                inside = validity(t_in, -2, P)   # the padded tile's positions outside the plane are zero padding
+                if inside is not None:
+                    cells = cells * inside
+                skips = skip1[:, :, 2:-2, 2:-2]
+            else:
+                act, skip = self._run(crop, 0, n - 1)       # level n-1: [F,C,(y1-y0) s_in,(x1-x0) s_in]
+                # the padding is only ever read where the crop ends at the plane's own border: zeros, as the reference pads
+                cells = tile_windows(act, s_in, 2, P)
+                skips = tile_windows(skip, s_in, 0, t_in)
+            vals = self._mosaic(self.upsample_blocks[n - 1], cells, validity(t_out, -4, 2 * P), p, 1)
+            vals = vals[:, :, 4:4 + t_out, 4:4 + t_out] + self.skip_connections[n - 1](skips)
             ov.view(F, C, 3, g, t_out, g, t_out)[f_idx, :, p, ty, :, tx, :] = vals
+        return out
+
+    def _mosaic(self, block, cells, valid, plane, stage):
+        """One UpsampleBlock over cells [K,C,p,p] -> [K,C,2p,2p].  The cells are laid out as ONE mosaic image, 8 cells
+        wide (the library then runs its large-image Winograd kernels whatever K is; a batch of small tiles made it pick
+        an implicit-GEMM kernel at half the speed); neighbouring cells only see each other inside the halos the caller
+        cuts away.  `valid` [K,1,2p,2p]: positions inside the plane (zero padding elsewhere, see _last_block).  Mosaic
+        heights only grow, and an image stays below MAX_ACTIVATION_BYTES."""
+        K, C, P, _ = cells.shape
+        cols = 8
+        if not hasattr(self, "_tile_batch"):
+            self._tile_batch = {}
+        rows = max(self._tile_batch.get((plane, stage), 0), -(-K // cols))
+        self._tile_batch[(plane, stage)] = rows
+        max_rows = max(1, self.MAX_ACTIVATION_BYTES // (C * 4 * P * P * cols * cells.element_size()))
+        out = cells.new_empty(K, C, 2 * P, 2 * P)
+        for r0 in range(0, rows, max_rows):
+            nr = min(max_rows, rows - r0)
+            k0, k1 = r0 * cols, min(K, (r0 + nr) * cols)
+            if k0 >= K:
+                break
+            mosaic = cells.new_zeros(nr * cols, C, P, P)
+            mosaic[:k1 - k0] = cells[k0:k1]
+            image = mosaic.view(nr, cols, C, P, P).permute(2, 0, 3, 1, 4).reshape(1, C, nr * P, cols * P)
+            m_img = None
+            if valid is not None:
+                m = cells.new_ones(nr * cols, 1, 2 * P, 2 * P)
+                m[:k1 - k0] = valid[k0:k1]
+                m_img = m.view(nr, cols, 1, 2 * P, 2 * P).permute(2, 0, 3, 1, 4).reshape(1, 1, nr * 2 * P, cols * 2 * P)
+            res = self._last_block(block, image, m_img)
+            res = res.view(C, nr, 2 * P, cols, 2 * P).permute(1, 3, 0, 2, 4).reshape(nr * cols, C, 2 * P, 2 * P)
+            out[k0:k1] = res[:k1 - k0]
         return out
 
 

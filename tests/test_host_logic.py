@@ -195,7 +195,7 @@ def test_windowed_upsampler_equals_full_planes_where_it_claims_to():
             # a body-like box off centre (tiles), one that touches the -x / +z borders (whole crop), one that needs all
             for case, (lo, hi) in enumerate((((-0.25, -0.6, -0.1), (0.3, 0.55, 0.2)), ((-1.4, -0.2, 0.9), (-1.0, 0.1, 1.4)),
                                              ((-1.3, -1.3, -1.3), (1.3, 1.3, 1.3)))):
-                up._window_sizes, up._tile_batch = [[0, 0] for _ in range(3)], [0, 0, 0]
+                up._window_sizes, up._tile_batch = [[0, 0] for _ in range(3)], {}
                 pts = torch.rand(2, 300, 3, generator=g) * (torch.tensor(hi) - torch.tensor(lo)) + torch.tensor(lo)
                 plan = up.plan_windows(pts, R, radius)
                 assert up.windows_contain(plan, pts, R, radius)
