@@ -234,3 +234,38 @@ def test_windowed_upsampler_equals_full_planes_where_it_claims_to():
             again = up.plan_windows(one, R, radius)
             size = lambda pl: [(w["crop"][1] - w["crop"][0], w["crop"][3] - w["crop"][2]) for w in pl]
             assert size(again) == size(wide)
+
+
+def test_windowed_upsampler_degenerate_plans():
+    """Resolution not a multiple of the tile size, non-finite points, and a plane nobody samples: whole planes / nothing,
+    never a wrong tile."""
+    from types import SimpleNamespace
+
+    from audio_motion_avatar_amd.renderer import TriplaneUpsampler
+
+    up = TriplaneUpsampler(SimpleNamespace(triplane_feature_dim=4, num_upsample_blocks=2)).eval()
+    g = torch.Generator().manual_seed(0)
+    with torch.no_grad():
+        R = 6  # not a multiple of TILE_CELLS: every plane as a whole
+        tokens = torch.randn(1, 4, 3 * R * R, generator=g)
+        pts = torch.rand(1, 50, 3, generator=g) - 0.5
+        plan = up.plan_windows(pts, R, 1.4)
+        assert all(w["tiles"] is None and w["crop"] == (0, R, 0, R) for w in plan)
+        assert torch.allclose(up.forward_tokens_windowed(tokens, R, plan, out=torch.zeros(1, 4, 3 * 24 * 24)),
+                              up.forward_tokens(tokens, R), atol=1e-6)
+        assert up.windows_contain(plan, pts * 100, R, 1.4)  # whole planes contain everything
+        R = 8
+        tokens = torch.randn(1, 4, 3 * R * R, generator=g)
+        bad = pts.clone()
+        bad[0, 3, 1] = float("nan")
+        plan = up.plan_windows(bad, R, 1.4)
+        assert all(w["tiles"] is None for w in plan)
+        # points far outside the radius clamp onto the border texels: those tiles are planned (and exact)
+        far = torch.full((1, 5, 3), 50.0)
+        plan = up.plan_windows(far, R, 1.4)
+        got = up.forward_tokens_windowed(tokens, R, plan, out=torch.full((1, 4, 3 * 32 * 32), float("nan")))
+        full = up.forward_tokens(tokens, R)
+        gv, fv = got.view(1, 4, 3, 32, 32), full.view(1, 4, 3, 32, 32)
+        for p, w in enumerate(plan):
+            assert w["mask"][0, -1, -1] and int(w["mask"].sum()) == 1
+            assert (gv[0, :, p, -16:, -16:] - fv[0, :, p, -16:, -16:]).abs().max() <= 1e-5
