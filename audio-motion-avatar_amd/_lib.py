@@ -114,6 +114,8 @@ SIGNATURES = {
                                         c_float_p, c_float_p, c_float_p, ctypes.c_void_p]),
     "amav_bn_gelu": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, c_float_p, c_float_p, c_float_p, c_float_p,
                                     ctypes.c_void_p]),
+    "amav_rows_norm": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p,
+                                      c_float_p, ctypes.c_float, c_float_p, c_float_p, ctypes.c_void_p]),
     "amav_unpool_merge": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, c_float_p, c_float_p, c_float_p, c_float_p,
                                          ctypes.c_void_p, c_float_p, c_float_p, ctypes.c_void_p]),
     "amav_lbs_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.POINTER(BodyTables)]),

@@ -20,6 +20,7 @@
 //   amav_cluster_max       per-cluster channel maximum + BatchNorm(eval) + GELU                 (SerializedPooling)
 //   amav_bn_gelu           BatchNorm(eval) + GELU                                                (Embedding, Unpooling)
 //   amav_unpool_merge      skip = GELU(BN(x)); sum = skip + up[cluster]                        (SerializedUnpooling)
+//   amav_rows_norm         s = base + LN_a(x) (or base + x); n = LN_b(s): the residual + LayerNorm passes of a Block
 #include <climits>
 
 #include "amav_common.h"
@@ -508,6 +509,63 @@ __global__ __launch_bounds__(256) void unpool_merge_kernel(long long quads, int 
     sum[i] = make_float4(k.x + u.x, k.y + u.y, k.z + u.z, k.w + u.w);
 }
 
+// ---- residual + LayerNorm passes of a Block (pointtransformer_v3.py:595-615) -------------------------------------------
+//   s = base + (norm_a ? LN_a(x) : x);  n = LN_b(s)        rows of C = 32 .. 512 floats
+// covers `feat + cpe.2(cpe.1(conv))` followed by norm1, and `feat + attn` followed by norm2: one pass over the rows
+// instead of LayerNorm + add + LayerNorm.  G lanes share a row (C = 4 G V floats), 64 / G rows per wave; two-pass
+// mean / variance on the registers.
+template <int G, int V>
+__global__ __launch_bounds__(256) void rows_norm_kernel(long long rows, const float4 *__restrict__ x,
+                                                        const float4 *__restrict__ base, const float4 *__restrict__ wa,
+                                                        const float4 *__restrict__ ba, const float4 *__restrict__ wb,
+                                                        const float4 *__restrict__ bb, float eps,
+                                                        float4 *__restrict__ out_sum, float4 *__restrict__ out_norm) {
+    constexpr int kRow4 = G * V;  // float4s per row
+    constexpr float kInvC = 1.0f / (4.0f * kRow4);
+    const int lane = threadIdx.x & 63, sub = lane % G;
+    const long long row = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / G) + lane / G;
+    const bool live = row < rows;
+    const long long r = live ? row : rows - 1;
+    auto group_sum = [](float v) {
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        return v;
+    };
+    auto normalise = [&](float4 (&t)[V], const float4 *w, const float4 *b) {
+        float sum = 0.f;
+#pragma unroll
+        for (int v = 0; v < V; ++v) sum += (t[v].x + t[v].y) + (t[v].z + t[v].w);
+        const float mean = group_sum(sum) * kInvC;
+        float var = 0.f;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const float dx = t[v].x - mean, dy = t[v].y - mean, dz = t[v].z - mean, dw = t[v].w - mean;
+            var += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        }
+        const float rstd = 1.0f / sqrtf(group_sum(var) * kInvC + eps);
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const float4 wv = w[sub + G * v], bv = b[sub + G * v];
+            t[v] = make_float4((t[v].x - mean) * rstd * wv.x + bv.x, (t[v].y - mean) * rstd * wv.y + bv.y,
+                               (t[v].z - mean) * rstd * wv.z + bv.z, (t[v].w - mean) * rstd * wv.w + bv.w);
+        }
+    };
+    float4 t[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) t[v] = x[r * kRow4 + sub + G * v];
+    if (wa) normalise(t, wa, ba);
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        const float4 h = base[r * kRow4 + sub + G * v];
+        t[v] = make_float4(h.x + t[v].x, h.y + t[v].y, h.z + t[v].z, h.w + t[v].w);
+        if (live) out_sum[r * kRow4 + sub + G * v] = t[v];
+    }
+    normalise(t, wb, bb);
+#pragma unroll
+    for (int v = 0; v < V; ++v)
+        if (live) out_norm[r * kRow4 + sub + G * v] = t[v];
+}
+
 }  // namespace cloud
 }  // namespace amav
 
@@ -633,6 +691,30 @@ extern "C" int amav_bn_gelu(int64_t rows, int channels, const float *x, const fl
         quads, channels / 4, reinterpret_cast<const float4 *>(x), reinterpret_cast<const float4 *>(scale),
         reinterpret_cast<const float4 *>(shift), reinterpret_cast<float4 *>(out));
     return check_launch("amav_bn_gelu");
+}
+
+extern "C" int amav_rows_norm(int64_t rows, int channels, const float *x, const float *base, const float *weight_a,
+                              const float *bias_a, const float *weight_b, const float *bias_b, float eps, float *out_sum,
+                              float *out_norm, void *stream_) {
+    AMAV_REQUIRE(rows > 0 && (channels == 32 || channels == 64 || channels == 128 || channels == 256 || channels == 512),
+                 "amav_rows_norm: rows=%lld channels=%d (32, 64, 128, 256, 512 are built)", (long long)rows, channels);
+    AMAV_REQUIRE(x && base && weight_b && bias_b && out_sum && out_norm && (!weight_a == !bias_a), "amav_rows_norm: NULL pointer");
+    AMAV_REQUIRE(aligned16(x) && aligned16(base) && aligned16(weight_b) && aligned16(bias_b) && aligned16(out_sum) &&
+                     aligned16(out_norm) && (!weight_a || (aligned16(weight_a) && aligned16(bias_a))),
+                 "amav_rows_norm: buffers must be 16-byte aligned");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    auto f4 = [](const float *p) { return reinterpret_cast<const float4 *>(p); };
+#define AMAV_ROWS_NORM(G_, V_)                                                                                       \
+    cloud::rows_norm_kernel<G_, V_><<<(unsigned)((rows + 4 * (64 / G_) - 1) / (4 * (64 / G_))), 256, 0, stream>>>(   \
+        rows, f4(x), f4(base), f4(weight_a), f4(bias_a), f4(weight_b), f4(bias_b), eps,                              \
+        reinterpret_cast<float4 *>(out_sum), reinterpret_cast<float4 *>(out_norm))
+    if (channels == 32) AMAV_ROWS_NORM(8, 1);
+    else if (channels == 64) AMAV_ROWS_NORM(16, 1);
+    else if (channels == 128) AMAV_ROWS_NORM(32, 1);
+    else if (channels == 256) AMAV_ROWS_NORM(64, 1);
+    else AMAV_ROWS_NORM(64, 2);
+#undef AMAV_ROWS_NORM
+    return check_launch("amav_rows_norm");
 }
 
 extern "C" int amav_unpool_merge(int64_t rows, int channels, const float *x, const float *scale, const float *shift,

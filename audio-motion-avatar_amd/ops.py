@@ -713,3 +713,19 @@ def unpool_merge(x, scale, shift, up, cluster):
                                        _shaped(shift, "shift", (C,)).data_ptr(), up.data_ptr(), cluster.data_ptr(),
                                        skip.data_ptr(), total.data_ptr(), _stream()), "amav_unpool_merge")
     return skip, total
+
+
+def rows_norm(x, base, norm_b, norm_a=None):
+    """-> (s = base + (LayerNorm_a(x) if norm_a else x), LayerNorm_b(s)) for [n, C] rows, C in {32,...,512};
+    norm_a / norm_b are nn.LayerNorm modules (weight, bias, eps)."""
+    x, base = _contig(x, "x"), _contig(base, "base")
+    n, C = x.shape
+    if base.shape != x.shape:
+        raise AmavError("rows_norm: x and base must have the same shape")
+    out_sum, out_norm = torch.empty_like(x), torch.empty_like(x)
+    ptr = lambda t: _shaped(t.detach(), "norm parameter", (C,)).data_ptr()
+    check(_lib.lib().amav_rows_norm(n, C, x.data_ptr(), base.data_ptr(),
+                                    None if norm_a is None else ptr(norm_a.weight), None if norm_a is None else ptr(norm_a.bias),
+                                    ptr(norm_b.weight), ptr(norm_b.bias), float(norm_b.eps), out_sum.data_ptr(),
+                                    out_norm.data_ptr(), _stream()), "amav_rows_norm")
+    return out_sum, out_norm

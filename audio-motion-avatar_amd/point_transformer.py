@@ -122,7 +122,12 @@ class Block(nn.Module):
 
     def forward(self, feat, level, conv_in=None):
         x = self.cpe[0](feat if conv_in is None else conv_in, level)
-        feat = feat + self.cpe[2](self.cpe[1](x))
+        # feat += LayerNorm(cpe linear); norm1 -- and feat += attention; norm2 -- as one pass over the rows each
+        if feat.shape[1] in (32, 64, 128, 256, 512):
+            feat, n1 = ops.rows_norm(self.cpe[1](x), feat, self.norm1[0], norm_a=self.cpe[2])
+            feat, n2 = ops.rows_norm(self.attn(n1, level), feat, self.norm2[0])
+            return feat + self.mlp(n2)
+        feat = feat + self.cpe[2](self.cpe[1](x))  # other widths: library LayerNorm
         feat = feat + self.attn(self.norm1(feat), level)
         return feat + self.mlp(self.norm2(feat))
 

@@ -313,6 +313,9 @@ int amav_add_layernorm(int64_t rows, int dim, int64_t rows_per_batch, const floa
  *                       (segment_csr 'max' + BatchNorm(eval) + GELU, pointtransformer_v3.py:693-719)
  * amav_bn_gelu          out = gelu(x * scale + shift), [rows, C]                                    (:785-788,738-744)
  * amav_unpool_merge     skip = gelu(x * scale + shift); sum = skip + up[cluster[row]]               (:748-755)
+ * amav_rows_norm        out_sum = base + (weight_a ? LayerNorm_a(x) : x); out_norm = LayerNorm_b(out_sum), rows of
+ *                       channels in {32, 64, 128, 256, 512}: `feat + cpe(...)` + norm1 and `feat + attn` + norm2 of a
+ *                       Block in one pass each (:595-609); weight_a / bias_a may both be NULL.
  */
 int amav_cloud_voxelize(int64_t n, int clouds, const float *points_dev, const int32_t *cloud_of_dev, float resolution,
                         int32_t *grid_dev, int32_t *cloud_depth_dev, int32_t *bounds_dev, void *stream);
@@ -333,6 +336,9 @@ int amav_cluster_max(int64_t clusters, int channels, const float *x_dev, const i
                      const int64_t *seg_dev, const float *scale_dev, const float *shift_dev, float *out_dev, void *stream);
 int amav_bn_gelu(int64_t rows, int channels, const float *x_dev, const float *scale_dev, const float *shift_dev,
                  float *out_dev, void *stream);
+int amav_rows_norm(int64_t rows, int channels, const float *x_dev, const float *base_dev, const float *weight_a_dev,
+                   const float *bias_a_dev, const float *weight_b_dev, const float *bias_b_dev, float eps,
+                   float *out_sum_dev, float *out_norm_dev, void *stream);
 int amav_unpool_merge(int64_t rows, int channels, const float *x_dev, const float *scale_dev, const float *shift_dev,
                       const float *up_dev, const int64_t *cluster_dev, float *skip_dev, float *sum_dev, void *stream);
 
