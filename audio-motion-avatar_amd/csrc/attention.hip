@@ -219,6 +219,272 @@ __global__ __launch_bounds__(256) void combine_kernel(const float *__restrict__ 
     *reinterpret_cast<float4 *>(orow) = make_float4(o0 * inv, o1 * inv, o2 * inv, o3 * inv);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same attention on the bf16 matrix instructions, fp32-equivalent: every fp32 operand x is split into three bf16
+// parts x = x1 + x2 + x3 (x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2): 24 mantissa bits, the subtractions
+// are exact), and a product is the six partial products x_i y_j with i + j <= 4, each EXACT in the fp32 accumulator
+// of v_mfma_f32_32x32x16_bf16; the dropped terms are below 2^-24 of the product, the size of one fp32 rounding
+// (tools/attention_accuracy.py: 1.6e-7 max abs against fp64, the fp32-MFMA kernel 2.3e-7, the library's SDPA 4.8e-7).
+// Six bf16 MFMAs cost 6/16 of the fp32 MFMA they replace (the bf16 pipe is 16x the fp32 one on gfx950).
+//   split_kv_kernel: K parts [3][B H][S][64] and V^T parts [3][B H][64][S_pad] in bf16, written once per call (every
+//     one of the 50 query tiles would otherwise split the same K / V again);
+//   selfattn_split_kernel: same decomposition as selfattn_kernel (128 queries per workgroup, transposed scores so the
+//     softmax stays in registers, key range split over workgroups); S^T = sum K_i Q_j^T with K rows read straight from
+//     a row-major LDS tile (16 B per lane), P^T split in registers and used as the B operand of O^T = sum V_i^T P_j^T
+//     (accumulator-as-operand: its k order inside a step is key 16 s + 8 (j >> 2) + 4 h + (j & 3), which is how the V^T
+//     fragments are gathered).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kLdK = kD + 8;   // bf16 per K row in LDS (144 B: 16-byte reads of 8 consecutive lanes cover all banks)
+constexpr int kLdV = kBN + 4;  // bf16 per V^T row in LDS (136 B: 8-byte reads of 16 consecutive lanes cover all banks)
+
+__device__ __forceinline__ void split3(float x, __bf16 &a, __bf16 &b, __bf16 &c) {
+    a = (__bf16)x;
+    const float r1 = x - (float)a;
+    b = (__bf16)r1;
+    c = (__bf16)(r1 - (float)b);
+}
+
+// grid (key tiles of 64, H, B), 256 threads: a [64 keys][64 d] tile of K and of V of one head
+__global__ __launch_bounds__(256) void split_kv_kernel(const float *__restrict__ k, const float *__restrict__ v, int S,
+                                                       int Spad, long long row_stride, __bf16 *__restrict__ Kp,
+                                                       __bf16 *__restrict__ Vt) {
+    __shared__ float vt[kD][kBN + 1];
+    const int tid = threadIdx.x, head = blockIdx.y, b = blockIdx.z, H = gridDim.y, B = gridDim.z;
+    const int key0 = blockIdx.x * kBN;
+    const size_t bh = (size_t)b * H + head, part_k = (size_t)B * H * S * kD, part_v = (size_t)B * H * kD * Spad;
+    // thread -> key tid / 4, 16 consecutive d at (tid % 4) * 16
+    const int key = tid >> 2, d0 = (tid & 3) * 16;
+    const bool live = key0 + key < S;
+    const size_t src = ((size_t)b * S + min(key0 + key, S - 1)) * row_stride + head * kD + d0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 kv = *reinterpret_cast<const float4 *>(k + src + 4 * q);
+        const float4 vv = *reinterpret_cast<const float4 *>(v + src + 4 * q);
+        const float kk[4] = {kv.x, kv.y, kv.z, kv.w};
+        bf16x4 p1, p2, p3;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            __bf16 a, bb, c;
+            split3(kk[e], a, bb, c);
+            p1[e] = a, p2[e] = bb, p3[e] = c;
+        }
+        if (live) {
+            __bf16 *dst = Kp + (bh * S + key0 + key) * kD + d0 + 4 * q;
+            *reinterpret_cast<bf16x4 *>(dst) = p1;
+            *reinterpret_cast<bf16x4 *>(dst + part_k) = p2;
+            *reinterpret_cast<bf16x4 *>(dst + 2 * part_k) = p3;
+        }
+        vt[d0 + 4 * q + 0][key] = live ? vv.x : 0.f;
+        vt[d0 + 4 * q + 1][key] = live ? vv.y : 0.f;
+        vt[d0 + 4 * q + 2][key] = live ? vv.z : 0.f;
+        vt[d0 + 4 * q + 3][key] = live ? vv.w : 0.f;
+    }
+    __syncthreads();
+    // thread -> d tid / 4, 16 consecutive keys at (tid % 4) * 16 (keys past S are zeros: the padded tail)
+    const int d = tid >> 2, kq = (tid & 3) * 16;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        bf16x4 p1, p2, p3;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            __bf16 a, bb, c;
+            split3(vt[d][kq + 4 * q + e], a, bb, c);
+            p1[e] = a, p2[e] = bb, p3[e] = c;
+        }
+        __bf16 *dst = Vt + (bh * kD + d) * Spad + key0 + kq + 4 * q;
+        *reinterpret_cast<bf16x4 *>(dst) = p1;
+        *reinterpret_cast<bf16x4 *>(dst + part_v) = p2;
+        *reinterpret_cast<bf16x4 *>(dst + 2 * part_v) = p3;
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void selfattn_split_kernel(const float *__restrict__ q, const __bf16 *__restrict__ Kp,
+                                                             const __bf16 *__restrict__ Vt, float *__restrict__ out,
+                                                             int S, int Spad, long long row_stride,
+                                                             long long out_row_stride, float scale_log2e, int nsplit,
+                                                             float *__restrict__ part) {
+    __shared__ __bf16 Ks[3][kBN * kLdK];  // [part][key][d]
+    __shared__ __bf16 Vs[3][kD * kLdV];   // [part][d][key]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int r = lane & 31, hh = lane >> 5;
+    const int head = blockIdx.y, b = blockIdx.z, H = gridDim.y, B = gridDim.z;
+    const int split = blockIdx.x % nsplit;
+    const int q0 = (blockIdx.x / nsplit) * kBM + wave * 32;
+    const size_t bh = (size_t)b * H + head, part_k = (size_t)B * H * S * kD, part_v = (size_t)B * H * kD * Spad;
+
+    // Q fragments (B operand of S^T = K Q^T): lane (r, hh) holds Q[q0 + r][16 s + 8 hh + j], pre-scaled, three parts
+    bf16x8 Q1[4], Q2[4], Q3[4];
+    {
+        const float *qrow = q + ((size_t)b * S + min(q0 + r, S - 1)) * row_stride + head * kD;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float4 lo = *reinterpret_cast<const float4 *>(qrow + 16 * s + 8 * hh);
+            const float4 hi = *reinterpret_cast<const float4 *>(qrow + 16 * s + 8 * hh + 4);
+            const float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                __bf16 a, bb, c;
+                split3(x[j] * scale_log2e, a, bb, c);
+                Q1[s][j] = a, Q2[s][j] = bb, Q3[s][j] = c;
+            }
+        }
+    }
+    f32x16 O0, O1;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) O0[t] = 0.f, O1[t] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;
+
+    const int ntiles_all = (S + kBN - 1) / kBN;
+    const int kt_begin = (int)((long long)ntiles_all * split / nsplit);
+    const int ntiles = (int)((long long)ntiles_all * (split + 1) / nsplit);
+    // staging map: 16-byte chunk number tid + 256 i of a [64 rows][128 B] tile: row (tid + 256 i) / 8, chunk % 8; the
+    // next tile's twelve chunks are in flight under the current tile's MFMAs (named registers: an indexed array captured
+    // by a lambda was demoted to scratch memory)
+    const int srow0 = tid >> 3, sc8 = (tid & 7) * 8;  // chunk i: row srow0 + 32 i
+    uint4 ka0, ka1, kb0, kb1, kc0, kc1, va0, va1, vb0, vb1, vc0, vc1;
+#define AMAV_SP_LOAD(kt_)                                                                                          \
+    {                                                                                                              \
+        const int key0_ = (kt_) * kBN;                                                                             \
+        const size_t k0_ = (bh * S + min(key0_ + srow0, S - 1)) * kD + sc8;                                        \
+        const size_t k1_ = (bh * S + min(key0_ + srow0 + 32, S - 1)) * kD + sc8;                                   \
+        const size_t v0_ = (bh * kD + srow0) * Spad + key0_ + sc8, v1_ = v0_ + (size_t)32 * Spad;                  \
+        ka0 = *reinterpret_cast<const uint4 *>(Kp + k0_), ka1 = *reinterpret_cast<const uint4 *>(Kp + k1_);        \
+        kb0 = *reinterpret_cast<const uint4 *>(Kp + part_k + k0_), kb1 = *reinterpret_cast<const uint4 *>(Kp + part_k + k1_); \
+        kc0 = *reinterpret_cast<const uint4 *>(Kp + 2 * part_k + k0_), kc1 = *reinterpret_cast<const uint4 *>(Kp + 2 * part_k + k1_); \
+        va0 = *reinterpret_cast<const uint4 *>(Vt + v0_), va1 = *reinterpret_cast<const uint4 *>(Vt + v1_);        \
+        vb0 = *reinterpret_cast<const uint4 *>(Vt + part_v + v0_), vb1 = *reinterpret_cast<const uint4 *>(Vt + part_v + v1_); \
+        vc0 = *reinterpret_cast<const uint4 *>(Vt + 2 * part_v + v0_), vc1 = *reinterpret_cast<const uint4 *>(Vt + 2 * part_v + v1_); \
+    }
+#define AMAV_SP_STAGE(p_, i_, kr_, vr_)                                                              \
+    {                                                                                                \
+        *reinterpret_cast<uint4 *>(&Ks[p_][(srow0 + 32 * (i_)) * kLdK + sc8]) = kr_;                 \
+        uint2 *d_ = reinterpret_cast<uint2 *>(&Vs[p_][(srow0 + 32 * (i_)) * kLdV + sc8]); /* 136-byte rows: 8-byte aligned */ \
+        d_[0] = make_uint2(vr_.x, vr_.y), d_[1] = make_uint2(vr_.z, vr_.w);                          \
+    }
+    AMAV_SP_LOAD(kt_begin)
+    for (int kt = kt_begin; kt < ntiles; ++kt) {
+        const int key0 = kt * kBN;
+        AMAV_SP_STAGE(0, 0, ka0, va0) AMAV_SP_STAGE(0, 1, ka1, va1) AMAV_SP_STAGE(1, 0, kb0, vb0)
+        AMAV_SP_STAGE(1, 1, kb1, vb1) AMAV_SP_STAGE(2, 0, kc0, vc0) AMAV_SP_STAGE(2, 1, kc1, vc1)
+        __syncthreads();
+        if (kt + 1 < ntiles) AMAV_SP_LOAD(kt + 1)
+
+        // ---- S^T = K Q^T, one 32-key half at a time: six partial products per 16-wide k-step
+        f32x16 S0, S1;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) S0[t] = 0.f, S1[t] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            f32x16 &Sx = kb ? S1 : S0;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int off = (r + 32 * kb) * kLdK + 16 * s + 8 * hh;
+                const bf16x8 a1 = *reinterpret_cast<const bf16x8 *>(&Ks[0][off]);
+                const bf16x8 a2 = *reinterpret_cast<const bf16x8 *>(&Ks[1][off]);
+                const bf16x8 a3 = *reinterpret_cast<const bf16x8 *>(&Ks[2][off]);
+                Sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, Q1[s], Sx, 0, 0, 0);  // small terms first
+                Sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, Q2[s], Sx, 0, 0, 0);
+                Sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, Q3[s], Sx, 0, 0, 0);
+                Sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, Q1[s], Sx, 0, 0, 0);
+                Sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, Q2[s], Sx, 0, 0, 0);
+                Sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, Q1[s], Sx, 0, 0, 0);
+            }
+        }
+        if ((kt + 1) * kBN > S) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int kk = key0 + (t & 3) + 8 * (t >> 2) + 4 * hh;
+                if (kk >= S) S0[t] = -1e30f;
+                if (kk + 32 >= S) S1[t] = -1e30f;
+            }
+        }
+        // ---- online softmax over this lane's query (as in selfattn_kernel)
+        float mx = S0[0];
+#pragma unroll
+        for (int t = 1; t < 16; ++t) mx = fmaxf(mx, S0[t]);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) mx = fmaxf(mx, S1[t]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float corr = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) O0[t] *= corr, O1[t] *= corr;
+        float psum = 0.f;
+        // ---- O^T += V^T P^T: the probabilities of registers 8 s2 .. 8 s2 + 7 are the B operand of k-step s2; element j
+        // of lane half hh is key 32 kb + 16 s2 + 8 (j >> 2) + 4 hh + (j & 3)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                bf16x8 P1, P2, P3;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float pv = __builtin_amdgcn_exp2f((kb ? S1[8 * s2 + j] : S0[8 * s2 + j]) - m_new);
+                    psum += pv;
+                    __bf16 a, bb, c;
+                    split3(pv, a, bb, c);
+                    P1[j] = a, P2[j] = bb, P3[j] = c;
+                }
+                const int kbase = 32 * kb + 16 * s2 + 4 * hh;
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const int off = (r + 32 * a) * kLdV + kbase;
+                    auto gather = [&](const __bf16 *base) {
+                        const bf16x4 lo = *reinterpret_cast<const bf16x4 *>(base + off);
+                        const bf16x4 hi = *reinterpret_cast<const bf16x4 *>(base + off + 8);
+                        bf16x8 x;
+                        x[0] = lo[0], x[1] = lo[1], x[2] = lo[2], x[3] = lo[3];
+                        x[4] = hi[0], x[5] = hi[1], x[6] = hi[2], x[7] = hi[3];
+                        return x;
+                    };
+                    const bf16x8 v1 = gather(Vs[0]), v2 = gather(Vs[1]), v3 = gather(Vs[2]);
+                    f32x16 &O = a ? O1 : O0;
+                    O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v3, P1, O, 0, 0, 0);
+                    O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v2, P2, O, 0, 0, 0);
+                    O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, P3, O, 0, 0, 0);
+                    O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v2, P1, O, 0, 0, 0);
+                    O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, P2, O, 0, 0, 0);
+                    O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, P1, O, 0, 0, 0);
+                }
+            }
+        l_run = l_run * corr + psum;
+        __syncthreads();
+    }
+#undef AMAV_SP_LOAD
+#undef AMAV_SP_STAGE
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    if (nsplit > 1) {
+        if (q0 + r < S) {
+            float *prow = part + ((((size_t)split * gridDim.z + b) * gridDim.y + head) * S + q0 + r) * (kD + 2);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = 8 * g + 4 * hh;
+                prow[d] = O0[4 * g], prow[d + 1] = O0[4 * g + 1], prow[d + 2] = O0[4 * g + 2], prow[d + 3] = O0[4 * g + 3];
+                prow[32 + d] = O1[4 * g], prow[33 + d] = O1[4 * g + 1], prow[34 + d] = O1[4 * g + 2];
+                prow[35 + d] = O1[4 * g + 3];
+            }
+            if (hh == 0) prow[kD] = m_run, prow[kD + 1] = l_tot;
+        }
+        return;
+    }
+    const float inv = 1.0f / l_tot;
+    if (q0 + r < S) {
+        float *orow = out + ((size_t)b * S + q0 + r) * out_row_stride + head * kD;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d = 8 * g + 4 * hh;
+            *reinterpret_cast<float4 *>(orow + d) =
+                make_float4(O0[4 * g] * inv, O0[4 * g + 1] * inv, O0[4 * g + 2] * inv, O0[4 * g + 3] * inv);
+            *reinterpret_cast<float4 *>(orow + 32 + d) =
+                make_float4(O1[4 * g] * inv, O1[4 * g + 1] * inv, O1[4 * g + 2] * inv, O1[4 * g + 3] * inv);
+        }
+    }
+}
+
 // Key-range split that best balances the (q-tile, head, batch) workgroups over the chip: a CU runs two workgroups
 // at a time (LDS / registers), so the kernel lasts ceil(blocks * s / CUs) slices of 1/s of the key sweep.
 static int choose_split(int B, int S, int H, int num_cus) {
@@ -252,10 +518,27 @@ static int attn_num_cus() {
     return n;
 }
 
+// AMAV_ATTN=f32 selects the fp32-MFMA kernel, anything else (default) the bf16 x 3 split kernel
+static bool attn_use_split() {
+    static const bool v = [] {
+        const char *e = getenv("AMAV_ATTN");
+        return !(e && e[0] == 'f');
+    }();
+    return v;
+}
+
+static size_t attn_partial_bytes(int B, int S, int H, int ns) {
+    return ns > 1 ? align_up((size_t)ns * B * H * S * (attn::kD + 2) * sizeof(float), 256) : 256;
+}
+static size_t attn_spad(int S) { return ((size_t)S + attn::kBN - 1) / attn::kBN * attn::kBN; }
+
 extern "C" size_t amav_selfattn_workspace_bytes(int B, int S, int H, int D) {
     if (B <= 0 || S <= 0 || H <= 0 || D != attn::kD) return 0;
     const int ns = attn::choose_split(B, S, H, attn_num_cus());
-    return ns > 1 ? (size_t)ns * B * H * S * (attn::kD + 2) * sizeof(float) : 256;
+    size_t need = attn_partial_bytes(B, S, H, ns);
+    if (attn_use_split())  // K parts [3][B H][S][64] + V^T parts [3][B H][64][S_pad], bf16
+        need += align_up(3 * (size_t)B * H * S * attn::kD * 2, 256) + align_up(3 * (size_t)B * H * attn::kD * attn_spad(S) * 2, 256);
+    return need;
 }
 
 extern "C" int amav_selfattn_forward(int B, int S, int H, int D, const float *q, const float *k, const float *v,
@@ -272,13 +555,23 @@ extern "C" int amav_selfattn_forward(int B, int S, int H, int D, const float *q,
                  "amav_selfattn_forward: q/k/v/out must be 16-byte aligned");
     AMAV_REQUIRE(H <= 65535 && B <= 65535, "amav_selfattn_forward: grid too large");
     const int ns = attn::choose_split(B, S, H, attn_num_cus());
-    const size_t need = ns > 1 ? (size_t)ns * B * H * S * (attn::kD + 2) * sizeof(float) : 0;
-    if (ns > 1 && (workspace == nullptr || workspace_bytes < need))
+    const bool split = attn_use_split();
+    const size_t need = split || ns > 1 ? amav_selfattn_workspace_bytes(B, S, H, D) : 0;
+    if (need && (workspace == nullptr || workspace_bytes < need))
         return fail(AMAV_ERR_WORKSPACE, "amav_selfattn_forward: workspace %zu < required %zu", workspace_bytes, need);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const dim3 grid((unsigned)((S + attn::kBM - 1) / attn::kBM) * ns, H, B);
-    attn::selfattn_kernel<<<grid, 256, 0, stream>>>(q, k, v, out, S, row_stride, out_row_stride,
-                                                    scale * 1.4426950408889634f, ns, static_cast<float *>(workspace));
+    if (split) {
+        char *ws = static_cast<char *>(workspace);
+        const int Spad = (int)attn_spad(S);
+        __bf16 *Kp = reinterpret_cast<__bf16 *>(ws + attn_partial_bytes(B, S, H, ns));
+        __bf16 *Vt = reinterpret_cast<__bf16 *>(reinterpret_cast<char *>(Kp) + align_up(3 * (size_t)B * H * S * attn::kD * 2, 256));
+        attn::split_kv_kernel<<<dim3((unsigned)(Spad / attn::kBN), H, B), 256, 0, stream>>>(k, v, S, Spad, row_stride, Kp, Vt);
+        attn::selfattn_split_kernel<<<grid, 256, 0, stream>>>(q, Kp, Vt, out, S, Spad, row_stride, out_row_stride,
+                                                            scale * 1.4426950408889634f, ns, static_cast<float *>(workspace));
+    } else
+        attn::selfattn_kernel<<<grid, 256, 0, stream>>>(q, k, v, out, S, row_stride, out_row_stride,
+                                                        scale * 1.4426950408889634f, ns, static_cast<float *>(workspace));
     if (ns > 1) {
         const long long threads = (long long)B * H * S * 16;
         attn::combine_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, stream>>>(static_cast<const float *>(workspace),
