@@ -414,42 +414,57 @@ __global__ __launch_bounds__(256, 2) void selfattn_split_kernel(const float *__r
         for (int t = 0; t < 16; ++t) O0[t] *= corr, O1[t] *= corr;
         float psum = 0.f;
         // ---- O^T += V^T P^T: the probabilities of registers 8 s2 .. 8 s2 + 7 are the B operand of k-step s2; element j
-        // of lane half hh is key 32 kb + 16 s2 + 8 (j >> 2) + 4 hh + (j & 3)
+        // of lane half hh is key 32 kb + 16 s2 + 8 (j >> 2) + 4 hh + (j & 3).  Software pipeline: the exponentials and
+        // the three-way split of step u + 1 (~80 vector instructions) are issued between the twelve MFMAs of step u
+        // (an MFMA holds the SIMD's issue port for 8 of its 32 cycles), pinned with sched_group_barrier
+        auto parts = [&](int u, bf16x8 &P1, bf16x8 &P2, bf16x8 &P3) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                bf16x8 P1, P2, P3;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float pv = __builtin_amdgcn_exp2f((kb ? S1[8 * s2 + j] : S0[8 * s2 + j]) - m_new);
-                    psum += pv;
-                    __bf16 a, bb, c;
-                    split3(pv, a, bb, c);
-                    P1[j] = a, P2[j] = bb, P3[j] = c;
-                }
-                const int kbase = 32 * kb + 16 * s2 + 4 * hh;
-#pragma unroll
-                for (int a = 0; a < 2; ++a) {
-                    const int off = (r + 32 * a) * kLdV + kbase;
-                    auto gather = [&](const __bf16 *base) {
-                        const bf16x4 lo = *reinterpret_cast<const bf16x4 *>(base + off);
-                        const bf16x4 hi = *reinterpret_cast<const bf16x4 *>(base + off + 8);
-                        bf16x8 x;
-                        x[0] = lo[0], x[1] = lo[1], x[2] = lo[2], x[3] = lo[3];
-                        x[4] = hi[0], x[5] = hi[1], x[6] = hi[2], x[7] = hi[3];
-                        return x;
-                    };
-                    const bf16x8 v1 = gather(Vs[0]), v2 = gather(Vs[1]), v3 = gather(Vs[2]);
-                    f32x16 &O = a ? O1 : O0;
-                    O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v3, P1, O, 0, 0, 0);
-                    O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v2, P2, O, 0, 0, 0);
-                    O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, P3, O, 0, 0, 0);
-                    O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v2, P1, O, 0, 0, 0);
-                    O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, P2, O, 0, 0, 0);
-                    O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, P1, O, 0, 0, 0);
-                }
+            for (int j = 0; j < 8; ++j) {
+                const float pv = __builtin_amdgcn_exp2f(((u >> 1) ? S1[8 * (u & 1) + j] : S0[8 * (u & 1) + j]) - m_new);
+                psum += pv;
+                __bf16 a, bb, c;
+                split3(pv, a, bb, c);
+                P1[j] = a, P2[j] = bb, P3[j] = c;
             }
+        };
+        bf16x8 Pc1, Pc2, Pc3, Pn1, Pn2, Pn3;
+        parts(0, Pc1, Pc2, Pc3);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {  // u = 2 kb + s2
+            const int kbase = 32 * (u >> 1) + 16 * (u & 1) + 4 * hh;
+            bf16x8 vf[2][3];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    const __bf16 *src = &Vs[p][(r + 32 * a) * kLdV + kbase];
+                    const bf16x4 lo = *reinterpret_cast<const bf16x4 *>(src);
+                    const bf16x4 hi = *reinterpret_cast<const bf16x4 *>(src + 8);
+                    vf[a][p][0] = lo[0], vf[a][p][1] = lo[1], vf[a][p][2] = lo[2], vf[a][p][3] = lo[3];
+                    vf[a][p][4] = hi[0], vf[a][p][5] = hi[1], vf[a][p][6] = hi[2], vf[a][p][7] = hi[3];
+                }
+            if (u + 1 < 4) parts(u + 1, Pn1, Pn2, Pn3);
+            O0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][2], Pc1, O0, 0, 0, 0);
+            O1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1][2], Pc1, O1, 0, 0, 0);
+            O0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][1], Pc2, O0, 0, 0, 0);
+            O1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1][1], Pc2, O1, 0, 0, 0);
+            O0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][0], Pc3, O0, 0, 0, 0);
+            O1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1][0], Pc3, O1, 0, 0, 0);
+            O0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][1], Pc1, O0, 0, 0, 0);
+            O1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1][1], Pc1, O1, 0, 0, 0);
+            O0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][0], Pc2, O0, 0, 0, 0);
+            O1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1][0], Pc2, O1, 0, 0, 0);
+            O0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][0], Pc1, O0, 0, 0, 0);
+            O1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1][0], Pc1, O1, 0, 0, 0);
+            if (u + 1 < 4) {
+#pragma unroll
+                for (int i = 0; i < 12; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);  // seven vector instructions of the next step
+                }
+                Pc1 = Pn1, Pc2 = Pn2, Pc3 = Pn3;
+            }
+        }
         l_run = l_run * corr + psum;
         __syncthreads();
     }
