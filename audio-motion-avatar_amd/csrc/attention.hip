@@ -300,18 +300,24 @@ __global__ __launch_bounds__(256) void split_kv_kernel(const float *__restrict__
     }
 }
 
+// Workgroup -> work mapping, XCD-aware: the hardware hands consecutive workgroup ids to the 8 XCDs in turn, and each XCD
+// has its own 4 MB L2.  Id i runs on XCD i % 8; the query tiles of ONE (batch, head, key-slice) -- which all stream the
+// same ~1 MB of K / V parts -- are given to one XCD back to back, so a slice stays in that XCD's L2 while its tiles run.
+// (Measured neutral at the reference shape, 0.55 ms either way: the kernel is not fetch-bound.)
 __global__ __launch_bounds__(256, 2) void selfattn_split_kernel(const float *__restrict__ q, const __bf16 *__restrict__ Kp,
                                                              const __bf16 *__restrict__ Vt, float *__restrict__ out,
                                                              int S, int Spad, long long row_stride,
                                                              long long out_row_stride, float scale_log2e, int nsplit,
-                                                             float *__restrict__ part) {
+                                                             float *__restrict__ part, int H, int B, int q_tiles) {
     __shared__ __bf16 Ks[3][kBN * kLdK];  // [part][key][d]
     __shared__ __bf16 Vs[3][kD * kLdV];   // [part][d][key]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r = lane & 31, hh = lane >> 5;
-    const int head = blockIdx.y, b = blockIdx.z, H = gridDim.y, B = gridDim.z;
-    const int split = blockIdx.x % nsplit;
-    const int q0 = (blockIdx.x / nsplit) * kBM + wave * 32;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int slice = (j / q_tiles) * 8 + xcd;  // (batch, head, key-slice) index
+    if (slice >= nsplit * H * B) return;        // whole workgroup: the grid is padded to 8 slices per round
+    const int split = slice % nsplit, head = (slice / nsplit) % H, b = slice / (nsplit * H);
+    const int q0 = (j % q_tiles) * kBM + wave * 32;
     const size_t bh = (size_t)b * H + head, part_k = (size_t)B * H * S * kD, part_v = (size_t)B * H * kD * Spad;
 
     // Q fragments (B operand of S^T = K Q^T): lane (r, hh) holds Q[q0 + r][16 s + 8 hh + j], pre-scaled, three parts
@@ -474,7 +480,7 @@ __global__ __launch_bounds__(256, 2) void selfattn_split_kernel(const float *__r
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     if (nsplit > 1) {
         if (q0 + r < S) {
-            float *prow = part + ((((size_t)split * gridDim.z + b) * gridDim.y + head) * S + q0 + r) * (kD + 2);
+            float *prow = part + ((((size_t)split * B + b) * H + head) * S + q0 + r) * (kD + 2);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int d = 8 * g + 4 * hh;
@@ -582,8 +588,11 @@ extern "C" int amav_selfattn_forward(int B, int S, int H, int D, const float *q,
         __bf16 *Kp = reinterpret_cast<__bf16 *>(ws + attn_partial_bytes(B, S, H, ns));
         __bf16 *Vt = reinterpret_cast<__bf16 *>(reinterpret_cast<char *>(Kp) + align_up(3 * (size_t)B * H * S * attn::kD * 2, 256));
         attn::split_kv_kernel<<<dim3((unsigned)(Spad / attn::kBN), H, B), 256, 0, stream>>>(k, v, S, Spad, row_stride, Kp, Vt);
-        attn::selfattn_split_kernel<<<grid, 256, 0, stream>>>(q, Kp, Vt, out, S, Spad, row_stride, out_row_stride,
-                                                            scale * 1.4426950408889634f, ns, static_cast<float *>(workspace));
+        const int q_tiles = (S + attn::kBM - 1) / attn::kBM;
+        const long long rounds = ((long long)ns * H * B + 7) / 8;  // 8 slices (one per XCD) per round
+        attn::selfattn_split_kernel<<<(unsigned)(rounds * 8 * q_tiles), 256, 0, stream>>>(
+            q, Kp, Vt, out, S, Spad, row_stride, out_row_stride, scale * 1.4426950408889634f, ns,
+            static_cast<float *>(workspace), H, B, q_tiles);
     } else
         attn::selfattn_kernel<<<grid, 256, 0, stream>>>(q, k, v, out, S, row_stride, out_row_stride,
                                                         scale * 1.4426950408889634f, ns, static_cast<float *>(workspace));
