@@ -557,30 +557,50 @@ def selfattn(q, k, v, heads, scale=None):
     return out
 
 
-def geglu(proj):
-    """proj [..., 2*inner] (contiguous, fp32) -> [..., inner] = proj[..., :inner] * gelu(proj[..., inner:]) (exact erf)."""
+def geglu(proj, bias=None):
+    """proj [..., 2*inner] (contiguous, fp32) -> [..., inner] = h * gelu(g) (exact erf) with h, g the two halves of
+    proj (+ bias [2*inner], when the projection's GEMM ran without it)."""
     proj = _need(proj, "proj")
     if not proj.is_contiguous() or proj.shape[-1] % 8:
         raise AmavError("geglu: need a contiguous [..., 2*inner] tensor with inner a multiple of 4")
     inner = proj.shape[-1] // 2
     out = torch.empty(*proj.shape[:-1], inner, device=proj.device)
-    check(_lib.lib().amav_geglu(proj.numel() // proj.shape[-1], inner, proj.data_ptr(), proj.shape[-1], out.data_ptr(),
-                                _stream()), "amav_geglu")
+    bias_ptr = None if bias is None else _shaped(bias, "bias", (2 * inner,)).data_ptr()
+    check(_lib.lib().amav_geglu(proj.numel() // proj.shape[-1], inner, proj.data_ptr(), proj.shape[-1], bias_ptr,
+                                out.data_ptr(), _stream()), "amav_geglu")
     return out
 
 
-def add_layernorm(hidden, add, batch_row, weight, bias, eps=1e-5):
-    """hidden [B,S,dim] (contiguous), add [B,S,dim] or None, batch_row [B,1,dim] or None ->
-    (h = batch_row + (add + hidden), LayerNorm(h) * weight + bias), two new tensors.  transformers.py:292-399."""
+def split_operand(x, weights=False):
+    """x [rows, k] fp32 (unit inner stride; k a multiple of 8) -> [rows, 6 k] bf16: the three-way bf16 split of x laid out
+    along K as the activation (default) or weight operand of an fp32-equivalent GEMM (include/amav.h,
+    amav_split_operand)."""
+    x = _need(x, "x")
+    if x.dim() != 2 or x.stride(1) != 1 or x.shape[1] % 8 or x.stride(0) % 4 or x.data_ptr() % 16:
+        raise AmavError("split_operand: need a 16-byte aligned [rows, k] tensor, unit inner stride, k a multiple of 8")
+    out = torch.empty(x.shape[0], 6 * x.shape[1], dtype=torch.bfloat16, device=x.device)
+    check(_lib.lib().amav_split_operand(x.shape[0], x.shape[1], x.data_ptr(), x.stride(0), int(bool(weights)),
+                                        out.data_ptr(), _stream()), "amav_split_operand")
+    return out
+
+
+def add_layernorm(hidden, add, batch_row, weight, bias, eps=1e-5, add_bias=None, split=False):
+    """hidden [B,S,dim] (contiguous), add [B,S,dim] or None (+ add_bias [dim]: the bias of the projection that produced
+    it), batch_row [B,1,dim] or None -> (h = batch_row + ((add + add_bias) + hidden), LayerNorm(h) * weight + bias), two
+    new tensors; with split=True the second is the [B*S, 6 dim] bf16 activation operand of the next projection
+    (split_operand's layout) instead of fp32 [B,S,dim].  transformers.py:292-399."""
     hidden = _need(hidden, "hidden")
     if hidden.dim() != 3 or not hidden.is_contiguous():
         raise AmavError("add_layernorm: hidden must be a contiguous [B,S,dim] tensor")
     B, S, dim = hidden.shape
     ptr = lambda t, name, shape: None if t is None else _shaped(t, name, shape).data_ptr()
-    h_out, out = torch.empty_like(hidden), torch.empty_like(hidden)
-    check(_lib.lib().amav_add_layernorm(B * S, dim, S, ptr(add, "add", (B, S, dim)), ptr(batch_row, "batch_row", (B, 1, dim)),
-                                        hidden.data_ptr(), h_out.data_ptr(), _shaped(weight, "weight", (dim,)).data_ptr(),
-                                        _shaped(bias, "bias", (dim,)).data_ptr(), float(eps), out.data_ptr(), _stream()),
+    h_out = torch.empty_like(hidden)
+    out = (torch.empty(B * S, 6 * dim, dtype=torch.bfloat16, device=hidden.device) if split else torch.empty_like(hidden))
+    check(_lib.lib().amav_add_layernorm(B * S, dim, S, ptr(add, "add", (B, S, dim)), ptr(add_bias, "add_bias", (dim,)),
+                                        ptr(batch_row, "batch_row", (B, 1, dim)), hidden.data_ptr(), h_out.data_ptr(),
+                                        _shaped(weight, "weight", (dim,)).data_ptr(),
+                                        _shaped(bias, "bias", (dim,)).data_ptr(), float(eps),
+                                        None if split else out.data_ptr(), out.data_ptr() if split else None, _stream()),
           "amav_add_layernorm")
     return h_out, out
 

@@ -7,18 +7,72 @@ Only the configuration AudioTriplaneNet uses is built (norm_type="layer_norm", G
 attention_bias=False, cross-attention to the audio token; triplane_audio_net.py:132-141).
 
 What runs where:
-  * self-attention (attn1, S = 6304 tokens, 8 x 64): the hand-written fp32 MFMA flash kernel (csrc/attention.hip),
+  * self-attention (attn1, S = 6304 tokens, 8 x 64): the hand-written MFMA flash kernel (csrc/attention.hip),
     fed by ONE fused q/k/v projection GEMM whose output it reads in place through a row stride;
   * cross-attention (attn2): the context is a single audio token (triplane_audio_net.py:211), so softmax over one
     key is exactly 1 and the layer is to_out(to_v(audio)) broadcast over the tokens -- computed exactly that way
     (two [1,768]x[768,512] products instead of 6304 x 512 x 2 of wasted Q/K work);
-  * LayerNorm / GroupNorm / Linear: library kernels through torch (rocBLAS / hipBLASLt fp32 GEMMs).
+  * the four big projections of a block (q/k/v, to_out, both feed-forward layers) at inference: `linear()` below --
+    an fp32-equivalent product on the bf16 matrix pipe (three-way bf16 split of both operands, six partial products as
+    one library bf16 GEMM with fp32 accumulation over K' = 6 K; csrc/attention.hip, split_operand_kernel), 1.5-2x
+    faster than the fp32 GEMM and closer to fp64.  AMAV_GEMM=f32 keeps the library's fp32 GEMM;
+  * GroupNorm, proj_in / proj_out, training / CPU: library kernels through torch (fp32 GEMMs).
 """
+import os
+import weakref
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
+
+_SPLIT_WEIGHTS = {}  # id(weight tensor) -> (weak reference to it, (version, data_ptr), its split operand [N, 6K] bf16)
+SPLIT_GEMM_MIN_ROWS = 256  # below this the operand split costs more than the faster GEMM saves
+SPLIT_GEMM_MAX_K = 1024    # above this too: the 2048 -> 512 feed-forward output projection ran 126 + 35 (split) us
+#                            against 120 us for the tuned fp32 GEMM (6304 rows; K' = 12288 leaves ~100 output tiles)
+
+
+def _split_weight(weight):
+    key = (weight._version, weight.data_ptr())
+    hit = _SPLIT_WEIGHTS.get(id(weight))
+    if hit is None or hit[0]() is not weight or hit[1] != key:
+        if hit is None or hit[0]() is not weight:
+            weakref.finalize(weight, _SPLIT_WEIGHTS.pop, id(weight), None)
+        hit = (weakref.ref(weight), key, ops.split_operand(weight.detach(), weights=True))
+        _SPLIT_WEIGHTS[id(weight)] = hit
+    return hit[2]
+
+
+def split_gemm_ok(rows, K):
+    """Whether a [rows, K] activation goes through the split GEMM (inference callers check device / dtype / autograd)."""
+    return (rows >= SPLIT_GEMM_MIN_ROWS and K % 8 == 0 and K <= SPLIT_GEMM_MAX_K
+            and os.environ.get("AMAV_GEMM", "split") != "f32")
+
+
+def linear_presplit(a, weight, bias=None):
+    """a: the [rows, 6 K] bf16 activation operand (ops.split_operand / ops.add_layernorm(split=True)) -> [rows, N] fp32
+    = x weight^T (+ bias).  A bias costs a pass over the output here (the library adds it as a pre-filled C): callers on
+    the hot path hand it to the kernel that consumes the result instead (ops.geglu / ops.add_layernorm)."""
+    b = _split_weight(weight)
+    if bias is None:
+        return torch.mm(a, b.t(), out_dtype=torch.float32)
+    return torch.addmm(bias, a, b.t(), out_dtype=torch.float32)
+
+
+def linear(x, weight, bias=None):
+    """F.linear(x, weight, bias) with an fp32-equivalent result.  On the inference path (fp32 CUDA tensors, no autograd,
+    at least SPLIT_GEMM_MIN_ROWS rows) the product runs on the bf16 matrix pipe over split operands (module docstring);
+    everywhere else it is F.linear."""
+    K = weight.shape[1]
+    rows = x.numel() // K
+    if (not x.is_cuda or x.dtype != torch.float32 or weight.dtype != torch.float32 or torch.is_grad_enabled()
+            or not split_gemm_ok(rows, K)):
+        return F.linear(x, weight, bias)
+    x2 = x.reshape(rows, K)
+    if x2.stride(1) != 1 or x2.stride(0) % 4 or x2.data_ptr() % 16:
+        x2 = x2.contiguous()
+    return linear_presplit(ops.split_operand(x2), weight, bias).view(*x.shape[:-1], weight.shape[0])
 
 
 class Attention(nn.Module):
@@ -44,6 +98,13 @@ class Attention(nn.Module):
             self._qkv = (version, torch.cat([w.detach() for w in ws], dim=0).contiguous())
         return self._qkv[1]
 
+    def attend(self, qkv, out_bias=True):
+        """qkv [B,S,3*inner] (the fused projection's output, read in place) -> to_out(softmax(q k^T / sqrt(d)) v);
+        out_bias=False leaves to_out's bias to the caller (forward_fused adds it in its next pass)."""
+        i = self.inner_dim
+        out = ops.selfattn(qkv[..., :i], qkv[..., i:2 * i], qkv[..., 2 * i:], self.heads)
+        return linear(out, self.to_out[0].weight, self.to_out[0].bias if out_bias else None)
+
     def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None):
         if attention_mask is not None:
             raise NotImplementedError("attention masks are not used on this path (transformers.py:1026-1031)")
@@ -51,11 +112,8 @@ class Attention(nn.Module):
             if torch.is_grad_enabled() and (hidden_states.requires_grad or self.to_q.weight.requires_grad):
                 raise NotImplementedError("the MFMA self-attention kernel is inference-only (no backward): run under "
                                           "torch.no_grad() / inference_mode (INTEGRATION.md)")
-            B, S, _ = hidden_states.shape
-            qkv = F.linear(hidden_states, self._qkv_weight())          # [B,S,3*inner], one GEMM
-            i = self.inner_dim
-            out = ops.selfattn(qkv[..., :i], qkv[..., i:2 * i], qkv[..., 2 * i:], self.heads)
-            return self.to_out[0](out)
+            qkv = linear(hidden_states, self._qkv_weight())            # [B,S,3*inner], one GEMM
+            return self.attend(qkv)
         if encoder_hidden_states.shape[1] != 1:
             # Many context tokens (stage 1: 4096 Sapiens tokens, triplane_net.py:104-113,320-329): a SURVEY 8(f)
             # next-row, on the library's fused attention (the MFMA kernel of csrc/attention.hip is the self-attention
@@ -79,7 +137,7 @@ class GEGLU(nn.Module):
         self.proj = nn.Linear(dim_in, dim_out * 2)
 
     def forward(self, hidden_states):
-        proj = self.proj(hidden_states)
+        proj = linear(hidden_states, self.proj.weight, self.proj.bias)
         if proj.is_cuda and proj.dtype == torch.float32 and not torch.is_grad_enabled() and proj.shape[-1] % 8 == 0:
             return ops.geglu(proj.contiguous())  # one fused pass (csrc/attention.hip)
         hidden_states, gate = proj.chunk(2, dim=-1)  # CPU construction / autograd
@@ -95,9 +153,8 @@ class FeedForward(nn.Module):
         self.net = nn.ModuleList([GEGLU(dim, inner), nn.Dropout(dropout), nn.Linear(inner, dim)])
 
     def forward(self, hidden_states):
-        for module in self.net:
-            hidden_states = module(hidden_states)
-        return hidden_states
+        hidden_states = self.net[1](self.net[0](hidden_states))
+        return linear(hidden_states, self.net[2].weight, self.net[2].bias)
 
 
 class BasicTransformerBlock(nn.Module):
@@ -117,6 +174,18 @@ class BasicTransformerBlock(nn.Module):
         has not happened yet (None for the first block), `row` [B,1,dim] this block's cross-attention output (one row per
         batch item: a single audio key).  -> (h, pending) with the same meaning.  Three residual adds and two
         LayerNorms run as two passes (ops.add_layernorm) instead of five."""
+        B, S, dim = h.shape
+        if split_gemm_ok(B * S, dim):
+            # the projections on the bf16 matrix pipe: each LayerNorm pass writes its rows as the split operand of the
+            # GEMM that follows, and the biases of to_out / the GEGLU projection are added by the pass that reads them
+            ff_in, ff_out = self.ff.net[0].proj, self.ff.net[2]
+            h, n1 = ops.add_layernorm(h, pending, None, self.norm1.weight, self.norm1.bias, self.norm1.eps, split=True)
+            qkv = linear_presplit(n1, self.attn1._qkv_weight()).view(B, S, -1)
+            a1 = self.attn1.attend(qkv, out_bias=False)
+            h, n3 = ops.add_layernorm(h, a1, row, self.norm3.weight, self.norm3.bias, self.norm3.eps,
+                                      add_bias=self.attn1.to_out[0].bias, split=True)
+            gated = ops.geglu(linear_presplit(n3, ff_in.weight).view(B, S, -1), bias=ff_in.bias)
+            return h, linear(gated, ff_out.weight, ff_out.bias)
         if pending is None:
             n1 = self.norm1(h)
         else:

@@ -149,6 +149,7 @@ def build_renderer(args, device, with_decoder=False):
 
 
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA = the fp32 vector peak
+MFMA_BF16_PEAK_TFLOPS = 2516.6  # dense bf16 MFMA: 32x32x16 in 32 cycles/SIMD, 1024 SIMDs, 2.4 GHz
 
 
 class FullPath:
@@ -221,8 +222,8 @@ class FullPath:
                 self.workspaces[ci] = ops.RasterWorkspace(fc, n, h, w, int(fc * max_frame * 1.25), self.device)
 
     def attention_roofline(self, ar_steps=3):
-        """HIP events around every self-attention launch (selfattn_kernel + its split-key combine) of `ar_steps`
-        transformer passes at the full shape."""
+        """HIP events around every self-attention launch (operand split + flash kernel + split-key combine) of
+        `ar_steps` transformer passes at the full shape."""
         from audio_motion_avatar_amd import ops
 
         net, L = self.net, len(self.net.transformer.transformer_blocks)
@@ -246,13 +247,28 @@ class FullPath:
         # one AR step: L x (q/k/v + out projections 4 * 2 S 512^2, GEGLU feed-forward 2 S 512 (4096 + 2048), attention)
         # + proj_in / proj_out 2 * 2 S 256 512
         step_flop = L * (flop + 2.0 * S * 512 * (4 * 512 + 4096 + 2048)) + 4.0 * S * 256 * 512
-        return {"bound": "mfma", "kernel": "selfattn_kernel + combine_kernel (fp32 MFMA flash attention, S=%d, H=%d)" % (S, H),
-                "achieved": flop / (ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": flop / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": ms,
-                "algorithmic_flop_per_launch": flop, "launches_timed": len(events),
-                "mfma_busy_frac": pmc_mfma_busy("selfattn_kernel"),
-                "transformer_step": {"ms": step_ms, "flop": step_flop, "achieved": step_flop / (step_ms * 1e-3) / 1e12,
-                                     "frac": step_flop / (step_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS}}
+        split = os.environ.get("AMAV_ATTN", "split") != "f32"
+        tf = flop / (ms * 1e-3) / 1e12
+        out = {"bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+               "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": ms,
+               "algorithmic_flop_per_launch": flop, "launches_timed": len(events),
+               "transformer_step": {"ms": step_ms, "flop": step_flop, "achieved": step_flop / (step_ms * 1e-3) / 1e12,
+                                    "frac": step_flop / (step_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS}}
+        if split:
+            # The product is fp32 in, fp32-equivalent out (1.6e-7 max abs against fp64, tools/attention_accuracy.py), so
+            # `achieved` / `peak` are the algorithmic fp32 FLOP against the fp32 MFMA peak, as for the fp32 kernel.  The
+            # arithmetic itself runs as six bf16 partial products per fp32 product on the bf16 matrix pipe: `pipe` prices
+            # the FLOP actually issued against THAT pipe's dense peak -- the figure that says how well the kernel uses
+            # the hardware it runs on.
+            out["kernel"] = ("split_kv_kernel + selfattn_split_kernel + combine_kernel (flash attention, bf16x3 split "
+                             "operands on the bf16 MFMA pipe, fp32-equivalent result, S=%d, H=%d)" % (S, H))
+            out["pipe"] = {"dtype": "bf16", "issued_flop_per_launch": 6.0 * flop, "achieved": 6.0 * tf,
+                           "peak": MFMA_BF16_PEAK_TFLOPS, "frac": 6.0 * tf / MFMA_BF16_PEAK_TFLOPS,
+                           "mfma_busy_frac": pmc_mfma_busy("selfattn_split_kernel")}
+        else:
+            out["kernel"] = "selfattn_kernel + combine_kernel (fp32 MFMA flash attention, S=%d, H=%d)" % (S, H)
+            out["mfma_busy_frac"] = pmc_mfma_busy("selfattn_kernel")
+        return out
 
     def cpu_baseline_and_parity(self, ar_steps=2):
         """Two autoregressive steps + their two rendered frames on the CPU oracle (a port), timed on this box's host

@@ -269,17 +269,30 @@ int amav_selfattn_forward(int batch, int seq_len, int heads, int head_dim, const
                           const float *v_dev, int64_t row_stride, float *out_dev, int64_t out_row_stride,
                           float scale, void *workspace, size_t workspace_bytes, void *stream);
 
+/* Operand of an fp32-equivalent nn.Linear (src/models/transformers.py:70-84, 448, 505: the to_q/k/v, to_out and
+ * feed-forward projections) computed as ONE bf16 GEMM with fp32 accumulation: x [rows, k] fp32 (row stride in floats) ->
+ * out [rows, 6 k] bf16, the three-way bf16 split x = x1 + x2 + x3 laid out along K as [x3 x2 x1 x2 x1 x1] (weights = 0,
+ * the activation side) or [w1 w2 w3 w1 w2 w1] (weights = 1), so that A' B'^T = the six partial products x_i w_j^T with
+ * i + j <= 4.  k must be a multiple of 8. */
+int amav_split_operand(int64_t rows, int k, const float *x_dev, int64_t x_row_stride, int weights, void *out_bf16_dev,
+                       void *stream);
+
 /* GEGLU gate of the transformer feed-forward (src/models/transformers.py:484-508, exact-erf GELU):
- * proj [rows, 2*inner] (row stride in floats) -> out [rows, inner] = proj[:, :inner] * gelu(proj[:, inner:]). */
-int amav_geglu(int64_t rows, int inner, const float *proj_dev, int64_t proj_row_stride, float *out_dev, void *stream);
+ * proj [rows, 2*inner] (row stride in floats) -> out [rows, inner] = proj[:, :inner] * gelu(proj[:, inner:]).
+ * bias [2*inner] (may be NULL) is added to proj first: the projection's bias when its GEMM ran without one. */
+int amav_geglu(int64_t rows, int inner, const float *proj_dev, int64_t proj_row_stride, const float *bias_dev,
+               float *out_dev, void *stream);
 
 /* Residual adds + LayerNorm of BasicTransformerBlock (src/models/transformers.py:292-399) in one pass over [rows, dim]
- * (dim in {256, 512, 768, 1024}):  h = (add + hidden);  h = (batch_row[row / rows_per_batch] + h);  hidden_out = h;
- * out_norm = LayerNorm(h) * weight + bias.  `add` [rows, dim] and `batch_row` [batches, dim] may be NULL; hidden_out
- * may alias hidden. */
-int amav_add_layernorm(int64_t rows, int dim, int64_t rows_per_batch, const float *add_dev, const float *batch_row_dev,
-                       const float *hidden_dev, float *hidden_out_dev, const float *weight_dev, const float *bias_dev,
-                       float eps, float *out_norm_dev, void *stream);
+ * (dim in {256, 512, 768, 1024}):  h = ((add + add_bias) + hidden);  h = (batch_row[row / rows_per_batch] + h);
+ * hidden_out = h;  norm = LayerNorm(h) * weight + bias.  `add` [rows, dim], `add_bias` [dim] (the bias of the projection
+ * that produced `add`, when its GEMM ran without one) and `batch_row` [batches, dim] may be NULL; hidden_out may alias
+ * hidden.  The normalised rows go to exactly one of out_norm (fp32 [rows, dim]) and out_norm_split (bf16 [rows, 6 dim],
+ * the activation operand of amav_split_operand, for the projection that follows); the other is NULL. */
+int amav_add_layernorm(int64_t rows, int dim, int64_t rows_per_batch, const float *add_dev, const float *add_bias_dev,
+                       const float *batch_row_dev, const float *hidden_dev, float *hidden_out_dev,
+                       const float *weight_dev, const float *bias_dev, float eps, float *out_norm_dev,
+                       void *out_norm_split_dev, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Point refiner: the sparse / serialised operators of the reference's
