@@ -71,11 +71,11 @@ SIGNATURES = {
     "amav_frames_to_rgb8": (ctypes.c_int, [ctypes.c_int64, c_float_p, ctypes.c_void_p, ctypes.c_void_p]),
     "amav_add_layernorm": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_int64, c_float_p, c_float_p, c_float_p,
                                           c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_float, c_float_p,
-                                          ctypes.c_void_p, ctypes.c_void_p]),
+                                          ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "amav_geglu": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, c_float_p, ctypes.c_int64, c_float_p, c_float_p,
-                                  ctypes.c_void_p]),
+                                  ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "amav_split_operand": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, c_float_p, ctypes.c_int64, ctypes.c_int,
-                                          ctypes.c_void_p, ctypes.c_void_p]),
+                                          ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     "amav_frames_wire_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64]),
     "amav_frames_pack_tiles": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_float_p,
                                               ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_int64,

@@ -239,6 +239,16 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int kLdK = kD + 8;   // bf16 per K row in LDS (144 B: 16-byte reads of 8 consecutive lanes cover all banks)
 constexpr int kLdV = kBN + 4;  // bf16 per V^T row in LDS (136 B: 8-byte reads of 16 consecutive lanes cover all banks)
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// Two-way fp16 split: x = h1 + h2 to 22 bits when the residual stays out of fp16's subnormals, which the callers arrange
+// by pre-scaling x with a power of two (exact) so that the tensor's bound sits just under fp16's maximum.
+__device__ __forceinline__ void split2(float x, _Float16 &a, _Float16 &b) {
+    a = (_Float16)x;
+    b = (_Float16)(x - (float)a);
+}
+
 __device__ __forceinline__ void split3(float x, __bf16 &a, __bf16 &b, __bf16 &c) {
     a = (__bf16)x;
     const float r1 = x - (float)a;
@@ -641,25 +651,69 @@ __global__ __launch_bounds__(256) void split_operand_kernel(long long octs, int 
         put(0, p3), put(1, p2), put(2, p1), put(3, p2), put(4, p1), put(5, p1);
     }
 }
+
+// fp16 x 2 format: (x * prescale) = h1 + h2; activations [h2 | h1 | h1], weights [g1 | g2 | g1] (K' = 3 K), so that
+// A' B'^T = h2 g1 + h1 g2 + h1 g1 -- the product to 2^-22, at half the MFMA work of the bf16 x 3 format.
+template <bool kWeights>
+__global__ __launch_bounds__(256) void split_operand_f16_kernel(long long octs, int k8, const float *__restrict__ x,
+                                                                long long row_stride, float prescale,
+                                                                _Float16 *__restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= octs) return;
+    const long long row = i / k8;
+    const int c = (int)(i - row * k8) * 8;
+    const float *src = x + row * row_stride + c;
+    const float4 lo = *reinterpret_cast<const float4 *>(src), hi = *reinterpret_cast<const float4 *>(src + 4);
+    const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    f16x8 p1, p2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        _Float16 a, b;
+        split2(v[j] * prescale, a, b);
+        p1[j] = a, p2[j] = b;
+    }
+    const long long K = (long long)k8 * 8;
+    _Float16 *dst = out + row * 3 * K + c;
+    auto put = [&](int block, const f16x8 &p) { *reinterpret_cast<f16x8 *>(dst + block * K) = p; };
+    if (kWeights) {
+        put(0, p1), put(1, p2), put(2, p1);
+    } else {
+        put(0, p2), put(1, p1), put(2, p1);
+    }
+}
 }  // namespace attn
 }  // namespace amav
 
-extern "C" int amav_split_operand(int64_t rows, int k, const float *x, int64_t x_row_stride, int weights, void *out_bf16,
-                                  void *stream) {
+static bool split_format_ok(int format, int scale_exp) {
+    return format == AMAV_SPLIT_BF16X3 || (format == AMAV_SPLIT_FP16X2 && scale_exp >= -126 && scale_exp <= 126);
+}
+
+extern "C" int amav_split_operand(int64_t rows, int k, const float *x, int64_t x_row_stride, int weights, int format,
+                                  int scale_exp, void *out, void *stream_) {
     AMAV_REQUIRE(rows > 0 && k > 0 && k % 8 == 0, "amav_split_operand: rows=%lld k=%d (k must be a multiple of 8)",
                  (long long)rows, k);
-    AMAV_REQUIRE(x && out_bf16, "amav_split_operand: NULL pointer");
+    AMAV_REQUIRE(x && out, "amav_split_operand: NULL pointer");
     AMAV_REQUIRE(x_row_stride >= k && x_row_stride % 4 == 0, "amav_split_operand: bad row stride");
-    AMAV_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out_bf16)) & 15) == 0,
+    AMAV_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0,
                  "amav_split_operand: buffers must be 16-byte aligned");
+    AMAV_REQUIRE(split_format_ok(format, scale_exp), "amav_split_operand: format %d / scale exponent %d", format, scale_exp);
     const long long octs = rows * (k / 8);
     const unsigned grid = (unsigned)((octs + 255) / 256);
-    if (weights)
-        amav::attn::split_operand_kernel<true><<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(
-            octs, k / 8, x, x_row_stride, static_cast<__bf16 *>(out_bf16));
-    else
-        amav::attn::split_operand_kernel<false><<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(
-            octs, k / 8, x, x_row_stride, static_cast<__bf16 *>(out_bf16));
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (format == AMAV_SPLIT_FP16X2) {
+        const float prescale = ldexpf(1.0f, scale_exp);
+        _Float16 *o = static_cast<_Float16 *>(out);
+        if (weights)
+            amav::attn::split_operand_f16_kernel<true><<<grid, 256, 0, stream>>>(octs, k / 8, x, x_row_stride, prescale, o);
+        else
+            amav::attn::split_operand_f16_kernel<false><<<grid, 256, 0, stream>>>(octs, k / 8, x, x_row_stride, prescale, o);
+    } else if (weights) {
+        amav::attn::split_operand_kernel<true><<<grid, 256, 0, stream>>>(octs, k / 8, x, x_row_stride,
+                                                                       static_cast<__bf16 *>(out));
+    } else {
+        amav::attn::split_operand_kernel<false><<<grid, 256, 0, stream>>>(octs, k / 8, x, x_row_stride,
+                                                                        static_cast<__bf16 *>(out));
+    }
     return check_launch("amav_split_operand");
 }
 
@@ -672,7 +726,8 @@ namespace amav {
 namespace attn {
 __global__ __launch_bounds__(256) void geglu_kernel(long long quads, int inner4, const float4 *__restrict__ in,
                                                     long long in_row4, const float4 *__restrict__ bias,
-                                                    float4 *__restrict__ out) {
+                                                    float4 *__restrict__ out, _Float16 *__restrict__ out_split,
+                                                    float prescale) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= quads) return;
     const long long row = i / inner4;
@@ -684,22 +739,43 @@ __global__ __launch_bounds__(256) void geglu_kernel(long long quads, int inner4,
         g = make_float4(g.x + bg.x, g.y + bg.y, g.z + bg.z, g.w + bg.w);
     }
     auto gelu = [](float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); };
-    out[i] = make_float4(h.x * gelu(g.x), h.y * gelu(g.y), h.z * gelu(g.z), h.w * gelu(g.w));
+    const float4 y = make_float4(h.x * gelu(g.x), h.y * gelu(g.y), h.z * gelu(g.z), h.w * gelu(g.w));
+    if (out_split) {  // the fp16 x 2 activation operand of the output projection (split_operand_f16_kernel's layout)
+        const float yv[4] = {y.x, y.y, y.z, y.w};
+        f16x4 p1, p2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            _Float16 a, b;
+            split2(yv[j] * prescale, a, b);
+            p1[j] = a, p2[j] = b;
+        }
+        const long long K = 4LL * inner4;
+        _Float16 *dst = out_split + row * 3 * K + 4 * col;
+        *reinterpret_cast<f16x4 *>(dst) = p2;
+        *reinterpret_cast<f16x4 *>(dst + K) = p1;
+        *reinterpret_cast<f16x4 *>(dst + 2 * K) = p1;
+    } else {
+        out[i] = y;
+    }
 }
 }  // namespace attn
 }  // namespace amav
 
 extern "C" int amav_geglu(int64_t rows, int inner, const float *proj, int64_t proj_row_stride, const float *bias,
-                          float *out, void *stream) {
+                          float *out, void *out_split, int split_scale_exp, void *stream) {
     AMAV_REQUIRE(rows > 0 && inner > 0 && inner % 4 == 0, "amav_geglu: bad sizes rows=%lld inner=%d", (long long)rows, inner);
-    AMAV_REQUIRE(proj && out, "amav_geglu: NULL pointer");
+    AMAV_REQUIRE(proj && ((out != nullptr) != (out_split != nullptr)),
+                 "amav_geglu: NULL projection, or not exactly one of out (fp32) and out_split (fp16 x 2 operand)");
+    AMAV_REQUIRE(split_scale_exp >= -126 && split_scale_exp <= 126, "amav_geglu: scale exponent %d", split_scale_exp);
     AMAV_REQUIRE(proj_row_stride >= 2LL * inner && proj_row_stride % 4 == 0, "amav_geglu: bad row stride");
-    AMAV_REQUIRE(((reinterpret_cast<uintptr_t>(proj) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0,
+    AMAV_REQUIRE(((reinterpret_cast<uintptr_t>(proj) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(bias) |
+                   reinterpret_cast<uintptr_t>(out_split)) & 15) == 0,
                  "amav_geglu: buffers must be 16-byte aligned");
     const long long quads = rows * (inner / 4);
     amav::attn::geglu_kernel<<<(unsigned)((quads + 255) / 256), 256, 0, static_cast<hipStream_t>(stream)>>>(
         quads, inner / 4, reinterpret_cast<const float4 *>(proj), proj_row_stride / 4,
-        reinterpret_cast<const float4 *>(bias), reinterpret_cast<float4 *>(out));
+        reinterpret_cast<const float4 *>(bias), reinterpret_cast<float4 *>(out), static_cast<_Float16 *>(out_split),
+        ldexpf(1.0f, split_scale_exp));
     return check_launch("amav_geglu");
 }
 
@@ -715,14 +791,15 @@ extern "C" int amav_geglu(int64_t rows, int inner, const float *proj, int64_t pr
 // fp32 -- the row never makes the round trip through HBM in between.
 namespace amav {
 namespace attn {
-template <int kVec, bool kSplit>  // float4 per lane: dim = 256 * kVec
+template <int kVec, int kSplit>  // float4 per lane: dim = 256 * kVec; kSplit 0: fp32 rows, 1: bf16 x 3, 2: fp16 x 2
 __global__ __launch_bounds__(256) void add_layernorm_kernel(long long rows, long long rows_per_batch,
                                                             const float4 *__restrict__ a, const float4 *__restrict__ a_bias,
                                                             const float4 *__restrict__ brow,
                                                             const float4 *__restrict__ h, float4 *__restrict__ h_out,
                                                             const float4 *__restrict__ w,
                                                             const float4 *__restrict__ b, float eps,
-                                                            float4 *__restrict__ out, __bf16 *__restrict__ out_split) {
+                                                            float4 *__restrict__ out, void *__restrict__ out_split,
+                                                            float prescale) {
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
@@ -768,7 +845,21 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(long long rows, long
         const float4 wv = w[c], bv = b[c];
         const float4 n = make_float4((x[v].x - mean) * rstd * wv.x + bv.x, (x[v].y - mean) * rstd * wv.y + bv.y,
                                      (x[v].z - mean) * rstd * wv.z + bv.z, (x[v].w - mean) * rstd * wv.w + bv.w);
-        if (kSplit) {
+        if (kSplit == 2) {
+            constexpr int K = 256 * kVec;
+            const float nv[4] = {n.x, n.y, n.z, n.w};
+            f16x4 p1, p2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                _Float16 s1, s2;
+                split2(nv[j] * prescale, s1, s2);
+                p1[j] = s1, p2[j] = s2;
+            }
+            _Float16 *dst = static_cast<_Float16 *>(out_split) + row * 3 * K + 4 * c;
+            *reinterpret_cast<f16x4 *>(dst) = p2;
+            *reinterpret_cast<f16x4 *>(dst + K) = p1;
+            *reinterpret_cast<f16x4 *>(dst + 2 * K) = p1;
+        } else if (kSplit == 1) {
             constexpr int K = 256 * kVec;
             const float nv[4] = {n.x, n.y, n.z, n.w};
             bf16x4 p1, p2, p3;
@@ -778,7 +869,7 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(long long rows, long
                 split3(nv[j], s1, s2, s3);
                 p1[j] = s1, p2[j] = s2, p3[j] = s3;
             }
-            __bf16 *dst = out_split + row * 6 * K + 4 * c;
+            __bf16 *dst = static_cast<__bf16 *>(out_split) + row * 6 * K + 4 * c;
             auto put = [&](int block, const bf16x4 &p) { *reinterpret_cast<bf16x4 *>(dst + block * K) = p; };
             put(0, p3), put(1, p2), put(2, p1), put(3, p2), put(4, p1), put(5, p1);
         } else {
@@ -791,13 +882,16 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(long long rows, long
 
 extern "C" int amav_add_layernorm(int64_t rows, int dim, int64_t rows_per_batch, const float *add, const float *add_bias,
                                   const float *batch_row, const float *hidden, float *hidden_out, const float *weight,
-                                  const float *bias, float eps, float *out_norm, void *out_norm_split, void *stream_) {
+                                  const float *bias, float eps, float *out_norm, void *out_norm_split, int split_format,
+                                  int split_scale_exp, void *stream_) {
     AMAV_REQUIRE(rows > 0 && rows_per_batch > 0 && (dim == 256 || dim == 512 || dim == 768 || dim == 1024),
                  "amav_add_layernorm: rows=%lld dim=%d (dim must be 256, 512, 768 or 1024)", (long long)rows, dim);
     AMAV_REQUIRE(hidden && hidden_out && weight && bias, "amav_add_layernorm: NULL pointer");
     AMAV_REQUIRE((out_norm != nullptr) != (out_norm_split != nullptr),
                  "amav_add_layernorm: give exactly one of out_norm (fp32) and out_norm_split (bf16 split operand)");
     AMAV_REQUIRE(add || !add_bias, "amav_add_layernorm: add_bias without add");
+    AMAV_REQUIRE(!out_norm_split || split_format_ok(split_format, split_scale_exp),
+                 "amav_add_layernorm: split format %d / scale exponent %d", split_format, split_scale_exp);
     AMAV_REQUIRE(((reinterpret_cast<uintptr_t>(hidden) | reinterpret_cast<uintptr_t>(hidden_out) |
                    reinterpret_cast<uintptr_t>(out_norm) | reinterpret_cast<uintptr_t>(out_norm_split) |
                    reinterpret_cast<uintptr_t>(add) | reinterpret_cast<uintptr_t>(add_bias) |
@@ -808,20 +902,23 @@ extern "C" int amav_add_layernorm(int64_t rows, int dim, int64_t rows_per_batch,
     const unsigned grid = (unsigned)((rows + 3) / 4);
     auto p4 = [](const float *p) { return reinterpret_cast<const float4 *>(p); };
     float4 *h4 = reinterpret_cast<float4 *>(hidden_out), *o4 = reinterpret_cast<float4 *>(out_norm);
-    __bf16 *os = static_cast<__bf16 *>(out_norm_split);
-#define AMAV_LN_LAUNCH(V)                                                                                             \
-    do {                                                                                                              \
-        if (os)                                                                                                       \
-            amav::attn::add_layernorm_kernel<V, true><<<grid, 256, 0, stream>>>(                                      \
-                rows, rows_per_batch, p4(add), p4(add_bias), p4(batch_row), p4(hidden), h4, p4(weight), p4(bias), eps, o4, os); \
-        else                                                                                                          \
-            amav::attn::add_layernorm_kernel<V, false><<<grid, 256, 0, stream>>>(                                     \
-                rows, rows_per_batch, p4(add), p4(add_bias), p4(batch_row), p4(hidden), h4, p4(weight), p4(bias), eps, o4, os); \
+    const float prescale = ldexpf(1.0f, out_norm_split && split_format == AMAV_SPLIT_FP16X2 ? split_scale_exp : 0);
+#define AMAV_LN_ARGS rows, rows_per_batch, p4(add), p4(add_bias), p4(batch_row), p4(hidden), h4, p4(weight), p4(bias), eps, \
+                     o4, out_norm_split, prescale
+#define AMAV_LN_LAUNCH(V)                                                                                   \
+    do {                                                                                                    \
+        if (!out_norm_split)                                                                                \
+            amav::attn::add_layernorm_kernel<V, 0><<<grid, 256, 0, stream>>>(AMAV_LN_ARGS);                 \
+        else if (split_format == AMAV_SPLIT_FP16X2)                                                         \
+            amav::attn::add_layernorm_kernel<V, 2><<<grid, 256, 0, stream>>>(AMAV_LN_ARGS);                 \
+        else                                                                                                \
+            amav::attn::add_layernorm_kernel<V, 1><<<grid, 256, 0, stream>>>(AMAV_LN_ARGS);                 \
     } while (0)
     if (dim == 256) AMAV_LN_LAUNCH(1);
     else if (dim == 512) AMAV_LN_LAUNCH(2);
     else if (dim == 768) AMAV_LN_LAUNCH(3);
     else AMAV_LN_LAUNCH(4);
 #undef AMAV_LN_LAUNCH
+#undef AMAV_LN_ARGS
     return check_launch("amav_add_layernorm");
 }

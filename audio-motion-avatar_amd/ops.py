@@ -557,51 +557,71 @@ def selfattn(q, k, v, heads, scale=None):
     return out
 
 
-def geglu(proj, bias=None):
+SPLIT_BF16X3, SPLIT_FP16X2 = 0, 1  # include/amav.h
+
+
+def _split_buffer(rows, k, fmt, device):
+    if fmt == SPLIT_FP16X2:
+        return torch.empty(rows, 3 * k, dtype=torch.float16, device=device)
+    if fmt == SPLIT_BF16X3:
+        return torch.empty(rows, 6 * k, dtype=torch.bfloat16, device=device)
+    raise AmavError(f"unknown split format {fmt}")
+
+
+def geglu(proj, bias=None, split_exp=None):
     """proj [..., 2*inner] (contiguous, fp32) -> [..., inner] = h * gelu(g) (exact erf) with h, g the two halves of
-    proj (+ bias [2*inner], when the projection's GEMM ran without it)."""
+    proj (+ bias [2*inner], when the projection's GEMM ran without it).  With split_exp the result is written as the
+    fp16 x 2 activation operand [rows, 3*inner] of the next projection, pre-scaled by 2^split_exp."""
     proj = _need(proj, "proj")
     if not proj.is_contiguous() or proj.shape[-1] % 8:
         raise AmavError("geglu: need a contiguous [..., 2*inner] tensor with inner a multiple of 4")
     inner = proj.shape[-1] // 2
-    out = torch.empty(*proj.shape[:-1], inner, device=proj.device)
+    rows = proj.numel() // proj.shape[-1]
+    if split_exp is None:
+        out = torch.empty(*proj.shape[:-1], inner, device=proj.device)
+    else:
+        out = _split_buffer(rows, inner, SPLIT_FP16X2, proj.device)
     bias_ptr = None if bias is None else _shaped(bias, "bias", (2 * inner,)).data_ptr()
-    check(_lib.lib().amav_geglu(proj.numel() // proj.shape[-1], inner, proj.data_ptr(), proj.shape[-1], bias_ptr,
-                                out.data_ptr(), _stream()), "amav_geglu")
+    check(_lib.lib().amav_geglu(rows, inner, proj.data_ptr(), proj.shape[-1], bias_ptr,
+                                out.data_ptr() if split_exp is None else None,
+                                None if split_exp is None else out.data_ptr(), int(split_exp or 0), _stream()),
+          "amav_geglu")
     return out
 
 
-def split_operand(x, weights=False):
-    """x [rows, k] fp32 (unit inner stride; k a multiple of 8) -> [rows, 6 k] bf16: the three-way bf16 split of x laid out
-    along K as the activation (default) or weight operand of an fp32-equivalent GEMM (include/amav.h,
-    amav_split_operand)."""
+def split_operand(x, weights=False, fmt=SPLIT_BF16X3, scale_exp=0):
+    """x [rows, k] fp32 (unit inner stride; k a multiple of 8) -> the activation (default) or weight operand of an
+    fp32-equivalent GEMM on the low-precision matrix pipe: [rows, 6 k] bf16 (SPLIT_BF16X3, any finite x) or [rows, 3 k]
+    fp16 of x * 2^scale_exp (SPLIT_FP16X2; the caller bounds |x| 2^scale_exp by 32768).  include/amav.h,
+    amav_split_operand."""
     x = _need(x, "x")
     if x.dim() != 2 or x.stride(1) != 1 or x.shape[1] % 8 or x.stride(0) % 4 or x.data_ptr() % 16:
         raise AmavError("split_operand: need a 16-byte aligned [rows, k] tensor, unit inner stride, k a multiple of 8")
-    out = torch.empty(x.shape[0], 6 * x.shape[1], dtype=torch.bfloat16, device=x.device)
-    check(_lib.lib().amav_split_operand(x.shape[0], x.shape[1], x.data_ptr(), x.stride(0), int(bool(weights)),
-                                        out.data_ptr(), _stream()), "amav_split_operand")
+    out = _split_buffer(x.shape[0], x.shape[1], fmt, x.device)
+    check(_lib.lib().amav_split_operand(x.shape[0], x.shape[1], x.data_ptr(), x.stride(0), int(bool(weights)), int(fmt),
+                                        int(scale_exp), out.data_ptr(), _stream()), "amav_split_operand")
     return out
 
 
-def add_layernorm(hidden, add, batch_row, weight, bias, eps=1e-5, add_bias=None, split=False):
+def add_layernorm(hidden, add, batch_row, weight, bias, eps=1e-5, add_bias=None, split=None, split_exp=0):
     """hidden [B,S,dim] (contiguous), add [B,S,dim] or None (+ add_bias [dim]: the bias of the projection that produced
     it), batch_row [B,1,dim] or None -> (h = batch_row + ((add + add_bias) + hidden), LayerNorm(h) * weight + bias), two
-    new tensors; with split=True the second is the [B*S, 6 dim] bf16 activation operand of the next projection
-    (split_operand's layout) instead of fp32 [B,S,dim].  transformers.py:292-399."""
+    new tensors; with split = SPLIT_BF16X3 / SPLIT_FP16X2 the second is the activation operand of the next projection
+    (split_operand's layout, pre-scaled by 2^split_exp for fp16) instead of fp32 [B,S,dim].  transformers.py:292-399."""
     hidden = _need(hidden, "hidden")
     if hidden.dim() != 3 or not hidden.is_contiguous():
         raise AmavError("add_layernorm: hidden must be a contiguous [B,S,dim] tensor")
     B, S, dim = hidden.shape
     ptr = lambda t, name, shape: None if t is None else _shaped(t, name, shape).data_ptr()
     h_out = torch.empty_like(hidden)
-    out = (torch.empty(B * S, 6 * dim, dtype=torch.bfloat16, device=hidden.device) if split else torch.empty_like(hidden))
+    out = torch.empty_like(hidden) if split is None else _split_buffer(B * S, dim, split, hidden.device)
     check(_lib.lib().amav_add_layernorm(B * S, dim, S, ptr(add, "add", (B, S, dim)), ptr(add_bias, "add_bias", (dim,)),
                                         ptr(batch_row, "batch_row", (B, 1, dim)), hidden.data_ptr(), h_out.data_ptr(),
                                         _shaped(weight, "weight", (dim,)).data_ptr(),
                                         _shaped(bias, "bias", (dim,)).data_ptr(), float(eps),
-                                        None if split else out.data_ptr(), out.data_ptr() if split else None, _stream()),
-          "amav_add_layernorm")
+                                        out.data_ptr() if split is None else None,
+                                        None if split is None else out.data_ptr(), int(split or 0), int(split_exp),
+                                        _stream()), "amav_add_layernorm")
     return h_out, out
 
 

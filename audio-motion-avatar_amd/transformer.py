@@ -12,12 +12,19 @@ What runs where:
   * cross-attention (attn2): the context is a single audio token (triplane_audio_net.py:211), so softmax over one
     key is exactly 1 and the layer is to_out(to_v(audio)) broadcast over the tokens -- computed exactly that way
     (two [1,768]x[768,512] products instead of 6304 x 512 x 2 of wasted Q/K work);
-  * the four big projections of a block (q/k/v, to_out, both feed-forward layers) at inference: `linear()` below --
-    an fp32-equivalent product on the bf16 matrix pipe (three-way bf16 split of both operands, six partial products as
-    one library bf16 GEMM with fp32 accumulation over K' = 6 K; csrc/attention.hip, split_operand_kernel), 1.5-2x
-    faster than the fp32 GEMM and closer to fp64.  AMAV_GEMM=f32 keeps the library's fp32 GEMM;
+  * the four big projections of a block (q/k/v, to_out, both feed-forward layers) at inference: fp32-equivalent
+    products on the low-precision matrix pipe -- both operands split into parts whose partial products are ONE library
+    GEMM with fp32 accumulation over the parts concatenated along K (csrc/attention.hip, split_operand kernels):
+      - inside a block (forward_fused) two fp16 parts, three partial products, K' = 3 K.  fp16 has 5 exponent bits, so
+        every operand is pre-scaled by a power of two (exact) taken from a PROVEN bound on its magnitude -- LayerNorm
+        rows are bounded by sqrt(dim) max|w| + max|b|, projections of them by Cauchy-Schwarz, softmax averages by their
+        values' bound (`_fp16_plan`) -- and the product is scaled back through the GEMM's alpha;
+      - `linear()` on inputs without such a bound: three bf16 parts, six partial products, K' = 6 K (any finite input).
+    Both are 2.5-3x / 1.5-2x faster than the library's fp32 GEMM and 2-3x closer to fp64 (tools/gemm_split_probe.py).
+    AMAV_GEMM=f32 keeps the fp32 GEMMs, AMAV_GEMM=bf16 the bf16 format everywhere;
   * GroupNorm, proj_in / proj_out, training / CPU: library kernels through torch (fp32 GEMMs).
 """
+import math
 import os
 import weakref
 
@@ -27,27 +34,67 @@ import torch.nn.functional as F
 
 from . import ops
 
-_SPLIT_WEIGHTS = {}  # id(weight tensor) -> (weak reference to it, (version, data_ptr), its split operand [N, 6K] bf16)
+_MEMO = {}  # (name, ids of the tensors it was derived from) -> (their versions, weak references, value)
 SPLIT_GEMM_MIN_ROWS = 256  # below this the operand split costs more than the faster GEMM saves
-SPLIT_GEMM_MAX_K = 1024    # above this too: the 2048 -> 512 feed-forward output projection ran 126 + 35 (split) us
+SPLIT_GEMM_MAX_K = 1024    # bf16 x 3 format only: the 2048 -> 512 feed-forward output projection ran 126 + 35 (split) us
 #                            against 120 us for the tuned fp32 GEMM (6304 rows; K' = 12288 leaves ~100 output tiles)
+FP16_TARGET = 32768.0      # a tensor's bound is scaled to at most this (fp16 max 65504: 2x margin for rounding)
 
 
-def _split_weight(weight):
-    key = (weight._version, weight.data_ptr())
-    hit = _SPLIT_WEIGHTS.get(id(weight))
-    if hit is None or hit[0]() is not weight or hit[1] != key:
-        if hit is None or hit[0]() is not weight:
-            weakref.finalize(weight, _SPLIT_WEIGHTS.pop, id(weight), None)
-        hit = (weakref.ref(weight), key, ops.split_operand(weight.detach(), weights=True))
-        _SPLIT_WEIGHTS[id(weight)] = hit
+def _memo(name, tensors, make):
+    """make() cached until one of `tensors` is modified in place, reallocated or freed."""
+    key = (name,) + tuple(id(t) for t in tensors)
+    version = tuple((t._version, t.data_ptr()) for t in tensors)
+    hit = _MEMO.get(key)
+    if hit is None or hit[0] != version or any(ref() is not t for ref, t in zip(hit[1], tensors)):
+        if hit is None or any(ref() is not t for ref, t in zip(hit[1], tensors)):
+            for t in tensors:
+                weakref.finalize(t, _MEMO.pop, key, None)
+        hit = (version, tuple(weakref.ref(t) for t in tensors), make())
+        _MEMO[key] = hit
     return hit[2]
 
 
+def _scale_exp(bound):
+    """The largest e with bound * 2^e <= FP16_TARGET."""
+    return max(-100, min(100, int(math.floor(math.log2(FP16_TARGET / max(float(bound), 1e-30))))))
+
+
+def _split_weight(weight):
+    return _memo("bf16x3", (weight,), lambda: ops.split_operand(weight.detach(), weights=True))
+
+
+def _split_weight_fp16(weight):
+    """-> (the fp16 x 2 weight operand [N, 3K], its scale exponent)"""
+    def make():
+        e = _scale_exp(weight.detach().abs().max().item())
+        return ops.split_operand(weight.detach(), weights=True, fmt=ops.SPLIT_FP16X2, scale_exp=e), e
+    return _memo("fp16x2", (weight,), make)
+
+
+_ZERO_BIAS = {}
+
+
+def gemm_fp16(a, a_exp, weight):
+    """a: fp16 x 2 activation operand [rows, 3K] pre-scaled by 2^a_exp -> [rows, N] fp32 = x weight^T, scaled back
+    exactly through the GEMM's alpha (beta = 0: the `input` of addmm is a placeholder)."""
+    b, b_exp = _split_weight_fp16(weight)
+    key = (a.device, weight.shape[0])
+    if key not in _ZERO_BIAS:
+        _ZERO_BIAS[key] = torch.zeros(weight.shape[0], device=a.device)
+    return torch.addmm(_ZERO_BIAS[key], a, b.t(), beta=0.0, alpha=2.0 ** -(a_exp + b_exp), out_dtype=torch.float32)
+
+
 def split_gemm_ok(rows, K):
-    """Whether a [rows, K] activation goes through the split GEMM (inference callers check device / dtype / autograd)."""
+    """Whether a [rows, K] activation goes through the bf16 x 3 split GEMM (inference callers check device / dtype /
+    autograd)."""
     return (rows >= SPLIT_GEMM_MIN_ROWS and K % 8 == 0 and K <= SPLIT_GEMM_MAX_K
             and os.environ.get("AMAV_GEMM", "split") != "f32")
+
+
+def fp16_gemm_ok(rows, K):
+    """Whether a block's projections go through the fp16 x 2 split GEMMs (forward_fused)."""
+    return rows >= SPLIT_GEMM_MIN_ROWS and K % 8 == 0 and os.environ.get("AMAV_GEMM", "split") == "split"
 
 
 def linear_presplit(a, weight, bias=None):
@@ -98,12 +145,17 @@ class Attention(nn.Module):
             self._qkv = (version, torch.cat([w.detach() for w in ws], dim=0).contiguous())
         return self._qkv[1]
 
-    def attend(self, qkv, out_bias=True):
+    def attend(self, qkv, out_bias=True, out_exp=None):
         """qkv [B,S,3*inner] (the fused projection's output, read in place) -> to_out(softmax(q k^T / sqrt(d)) v);
-        out_bias=False leaves to_out's bias to the caller (forward_fused adds it in its next pass)."""
+        out_bias=False leaves to_out's bias to the caller (forward_fused adds it in its next pass); out_exp: the scale
+        exponent of the attention output's proven bound, which sends to_out through the fp16 x 2 GEMM."""
         i = self.inner_dim
         out = ops.selfattn(qkv[..., :i], qkv[..., i:2 * i], qkv[..., 2 * i:], self.heads)
-        return linear(out, self.to_out[0].weight, self.to_out[0].bias if out_bias else None)
+        if out_exp is None:
+            return linear(out, self.to_out[0].weight, self.to_out[0].bias if out_bias else None)
+        a = ops.split_operand(out.view(-1, i), fmt=ops.SPLIT_FP16X2, scale_exp=out_exp)
+        y = gemm_fp16(a, out_exp, self.to_out[0].weight).view(*out.shape[:-1], -1)
+        return y + self.to_out[0].bias if out_bias else y
 
     def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None):
         if attention_mask is not None:
@@ -170,29 +222,77 @@ class BasicTransformerBlock(nn.Module):
         self.ff = FeedForward(dim, dropout=dropout)
 
     def forward_fused(self, h, pending, row):
-        """Inference path of Transformer1D_nn: `pending` is the previous block's feed-forward output whose residual add
-        has not happened yet (None for the first block), `row` [B,1,dim] this block's cross-attention output (one row per
-        batch item: a single audio key).  -> (h, pending) with the same meaning.  Three residual adds and two
-        LayerNorms run as two passes (ops.add_layernorm) instead of five."""
+        """Inference path of Transformer1D_nn: `pending` is the previous block's (feed-forward output, its bias or None)
+        whose residual add has not happened yet (None for the first block), `row` [B,1,dim] this block's cross-attention
+        output (one row per batch item: a single audio key).  -> (h, pending) with the same meaning.  Three residual
+        adds and two LayerNorms run as two passes (ops.add_layernorm) instead of five."""
         B, S, dim = h.shape
+        ff_in, ff_out = self.ff.net[0].proj, self.ff.net[2]
+        pending, pending_bias = pending if pending is not None else (None, None)
+        if fp16_gemm_ok(B * S, dim):
+            # every projection as an fp16 x 2 split GEMM: each pass writes its rows as the split operand of the GEMM that
+            # follows, pre-scaled from the proven bounds of _fp16_plan, and the projections' biases are added by the
+            # pass that reads their output
+            e_n1, e_attn, e_n3, e_ff = self._fp16_plan()
+            h, n1 = ops.add_layernorm(h, pending, None, self.norm1.weight, self.norm1.bias, self.norm1.eps,
+                                      add_bias=pending_bias, split=ops.SPLIT_FP16X2, split_exp=e_n1)
+            qkv = gemm_fp16(n1, e_n1, self.attn1._qkv_weight()).view(B, S, -1)
+            a1 = self.attn1.attend(qkv, out_bias=False, out_exp=e_attn)
+            h, n3 = ops.add_layernorm(h, a1, row, self.norm3.weight, self.norm3.bias, self.norm3.eps,
+                                      add_bias=self.attn1.to_out[0].bias, split=ops.SPLIT_FP16X2, split_exp=e_n3)
+            gated = ops.geglu(gemm_fp16(n3, e_n3, ff_in.weight), bias=ff_in.bias, split_exp=e_ff)
+            return h, (gemm_fp16(gated, e_ff, ff_out.weight).view(B, S, -1), ff_out.bias)
+        if pending is not None and pending_bias is not None:
+            pending = pending + pending_bias
         if split_gemm_ok(B * S, dim):
-            # the projections on the bf16 matrix pipe: each LayerNorm pass writes its rows as the split operand of the
-            # GEMM that follows, and the biases of to_out / the GEGLU projection are added by the pass that reads them
-            ff_in, ff_out = self.ff.net[0].proj, self.ff.net[2]
-            h, n1 = ops.add_layernorm(h, pending, None, self.norm1.weight, self.norm1.bias, self.norm1.eps, split=True)
+            # the bf16 x 3 format (AMAV_GEMM=bf16): no bounds needed
+            h, n1 = ops.add_layernorm(h, pending, None, self.norm1.weight, self.norm1.bias, self.norm1.eps,
+                                      split=ops.SPLIT_BF16X3)
             qkv = linear_presplit(n1, self.attn1._qkv_weight()).view(B, S, -1)
             a1 = self.attn1.attend(qkv, out_bias=False)
             h, n3 = ops.add_layernorm(h, a1, row, self.norm3.weight, self.norm3.bias, self.norm3.eps,
-                                      add_bias=self.attn1.to_out[0].bias, split=True)
+                                      add_bias=self.attn1.to_out[0].bias, split=ops.SPLIT_BF16X3)
             gated = ops.geglu(linear_presplit(n3, ff_in.weight).view(B, S, -1), bias=ff_in.bias)
-            return h, linear(gated, ff_out.weight, ff_out.bias)
+            return h, (linear(gated, ff_out.weight, ff_out.bias), None)
         if pending is None:
             n1 = self.norm1(h)
         else:
             h, n1 = ops.add_layernorm(h, pending, None, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         a1 = self.attn1(n1).contiguous()
         h, n3 = ops.add_layernorm(h, a1, row, self.norm3.weight, self.norm3.bias, self.norm3.eps)
-        return h, self.ff(n3)
+        return h, (self.ff(n3), None)
+
+    def _fp16_plan(self):
+        """Scale exponents (e_n1, e_attn, e_n3, e_ff) of the four activation operands of forward_fused, each from a bound
+        that holds for EVERY input:
+          LayerNorm rows n = z w + b with |z_i| <= sqrt(dim) and ||z||_2 <= sqrt(dim):
+              |n_i| <= sqrt(dim) max|w| + max|b|,      ||n||_2 <= sqrt(dim) max|w| + ||b||_2
+          a projection of such a row: |W_j n (+ c_j)| <= max_j ||W_j||_2 ||n||_2 (+ max|c|)        (Cauchy-Schwarz)
+          the attention output is a convex combination of value rows: |o_i| <= max|v|
+          GEGLU: |h gelu(g)| <= |h| |g|.
+        The bounds overshoot typical magnitudes by 2^4..2^9; fp16 keeps a value's residual exact down to 2^-18 of the
+        scaled bound, so the headroom only costs precision on elements that are already negligible."""
+        ff_in = self.ff.net[0].proj
+        tensors = (self.norm1.weight, self.norm1.bias, self.norm3.weight, self.norm3.bias, self.attn1.to_v.weight,
+                   ff_in.weight, ff_in.bias)
+
+        def make():
+            dim = self.norm1.weight.numel()
+            inner = ff_in.weight.shape[0] // 2
+            stats = torch.stack([
+                self.norm1.weight.abs().max(), self.norm1.bias.abs().max(), self.norm1.bias.norm(),
+                self.norm3.weight.abs().max(), self.norm3.bias.abs().max(), self.norm3.bias.norm(),
+                self.attn1.to_v.weight.norm(dim=1).max(),
+                ff_in.weight[:inner].norm(dim=1).max(), ff_in.weight[inner:].norm(dim=1).max(),
+                ff_in.bias[:inner].abs().max(), ff_in.bias[inner:].abs().max()]).double().tolist()  # one host sync
+            w1, b1, b1_l2, w3, b3, b3_l2, v_rows, h_rows, g_rows, h_bias, g_bias = stats
+            root = math.sqrt(dim)
+            n1_l2, n3_l2 = root * w1 + b1_l2, root * w3 + b3_l2
+            v_bound = v_rows * n1_l2 + (self.attn1.to_v.bias.abs().max().item() if self.attn1.to_v.bias is not None else 0.0)
+            ff_bound = (h_rows * n3_l2 + h_bias) * (g_rows * n3_l2 + g_bias)
+            return tuple(_scale_exp(b) for b in (root * w1 + b1, v_bound, root * w3 + b3, ff_bound))
+
+        return _memo("fp16_plan", tensors, make)
 
     def forward(self, hidden_states, encoder_hidden_states=None):
         h = hidden_states
@@ -260,7 +360,8 @@ class Transformer1D_nn(nn.Module):
             h, pending = h.contiguous(), None
             for block, row in zip(self.transformer_blocks, rows):
                 h, pending = block.forward_fused(h, pending, row)
-            h = pending + h
+            last, last_bias = pending  # the last feed-forward output (+ its bias, when its GEMM ran without one)
+            h = (last if last_bias is None else last + last_bias) + h
         else:
             for block in self.transformer_blocks:
                 h = block(h, ctx)

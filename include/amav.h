@@ -270,29 +270,39 @@ int amav_selfattn_forward(int batch, int seq_len, int heads, int head_dim, const
                           float scale, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Operand of an fp32-equivalent nn.Linear (src/models/transformers.py:70-84, 448, 505: the to_q/k/v, to_out and
- * feed-forward projections) computed as ONE bf16 GEMM with fp32 accumulation: x [rows, k] fp32 (row stride in floats) ->
- * out [rows, 6 k] bf16, the three-way bf16 split x = x1 + x2 + x3 laid out along K as [x3 x2 x1 x2 x1 x1] (weights = 0,
- * the activation side) or [w1 w2 w3 w1 w2 w1] (weights = 1), so that A' B'^T = the six partial products x_i w_j^T with
- * i + j <= 4.  k must be a multiple of 8. */
-int amav_split_operand(int64_t rows, int k, const float *x_dev, int64_t x_row_stride, int weights, void *out_bf16_dev,
-                       void *stream);
+ * feed-forward projections) computed as ONE low-precision GEMM with fp32 accumulation over operands split into parts
+ * and concatenated along K.  x [rows, k] fp32 (row stride in floats, k a multiple of 8) -> out [rows, parts * k]:
+ *   AMAV_SPLIT_BF16X3  x = x1 + x2 + x3 (bf16 each); activations (weights = 0) [x3 x2 x1 x2 x1 x1], weights (weights = 1)
+ *                      [w1 w2 w3 w1 w2 w1]: A' B'^T = the six partial products x_i w_j^T with i + j <= 4 (K' = 6 k).
+ *                      Any finite input; scale_exp is ignored.
+ *   AMAV_SPLIT_FP16X2  x 2^scale_exp = h1 + h2 (fp16 each); activations [h2 h1 h1], weights [g1 g2 g1]: A' B'^T =
+ *                      h2 g1 + h1 g2 + h1 g1 (K' = 3 k, half the matrix work).  The caller picks scale_exp from a bound
+ *                      on |x| so that |x| 2^scale_exp <= 32768 (no overflow) and typical values keep their residual out
+ *                      of fp16's subnormals, and multiplies the product by 2^-(scale_exp_a + scale_exp_w). */
+#define AMAV_SPLIT_BF16X3 0
+#define AMAV_SPLIT_FP16X2 1
+int amav_split_operand(int64_t rows, int k, const float *x_dev, int64_t x_row_stride, int weights, int format,
+                       int scale_exp, void *out_dev, void *stream);
 
 /* GEGLU gate of the transformer feed-forward (src/models/transformers.py:484-508, exact-erf GELU):
- * proj [rows, 2*inner] (row stride in floats) -> out [rows, inner] = proj[:, :inner] * gelu(proj[:, inner:]).
- * bias [2*inner] (may be NULL) is added to proj first: the projection's bias when its GEMM ran without one. */
+ * proj [rows, 2*inner] (row stride in floats) -> [rows, inner] = proj[:, :inner] * gelu(proj[:, inner:]).
+ * bias [2*inner] (may be NULL) is added to proj first: the projection's bias when its GEMM ran without one.
+ * The result goes to exactly one of out (fp32) and out_split (the AMAV_SPLIT_FP16X2 activation operand [rows, 3*inner]
+ * of the output projection, pre-scaled by 2^split_scale_exp); the other is NULL. */
 int amav_geglu(int64_t rows, int inner, const float *proj_dev, int64_t proj_row_stride, const float *bias_dev,
-               float *out_dev, void *stream);
+               float *out_dev, void *out_split_dev, int split_scale_exp, void *stream);
 
 /* Residual adds + LayerNorm of BasicTransformerBlock (src/models/transformers.py:292-399) in one pass over [rows, dim]
  * (dim in {256, 512, 768, 1024}):  h = ((add + add_bias) + hidden);  h = (batch_row[row / rows_per_batch] + h);
  * hidden_out = h;  norm = LayerNorm(h) * weight + bias.  `add` [rows, dim], `add_bias` [dim] (the bias of the projection
  * that produced `add`, when its GEMM ran without one) and `batch_row` [batches, dim] may be NULL; hidden_out may alias
- * hidden.  The normalised rows go to exactly one of out_norm (fp32 [rows, dim]) and out_norm_split (bf16 [rows, 6 dim],
- * the activation operand of amav_split_operand, for the projection that follows); the other is NULL. */
+ * hidden.  The normalised rows go to exactly one of out_norm (fp32 [rows, dim]) and out_norm_split (the activation
+ * operand of amav_split_operand in split_format / split_scale_exp, for the projection that follows); the other is
+ * NULL. */
 int amav_add_layernorm(int64_t rows, int dim, int64_t rows_per_batch, const float *add_dev, const float *add_bias_dev,
                        const float *batch_row_dev, const float *hidden_dev, float *hidden_out_dev,
                        const float *weight_dev, const float *bias_dev, float eps, float *out_norm_dev,
-                       void *out_norm_split_dev, void *stream);
+                       void *out_norm_split_dev, int split_format, int split_scale_exp, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Point refiner: the sparse / serialised operators of the reference's
