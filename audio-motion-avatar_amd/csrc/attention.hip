@@ -14,7 +14,10 @@
 //     O^T = V^T P^T -- the probabilities never leave the registers;
 //   * K is staged in LDS transposed ([d][key], padded) and V row-major, which makes every operand fetch a
 //     conflict-free 32-lane row read; the next K/V tile is prefetched into registers under the current tile's MFMAs.
+#include <algorithm>
+#include <cmath>
 #include <cstdlib>
+#include <cstring>
 
 #include "amav_common.h"
 
@@ -516,6 +519,294 @@ __global__ __launch_bounds__(256, 2) void selfattn_split_kernel(const float *__r
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// fp16 x 2 form of the split kernel: x 2^e = h1 + h2 with fp16 parts carries 22 bits, and a product needs THREE partial
+// products (h1 g1, h1 g2, h2 g1) instead of six -- half the MFMA work and two thirds of the LDS traffic.  fp16 has five
+// exponent bits, so every operand is pre-scaled by a power of two (exact) taken from its measured magnitude:
+//   absmax_kernel      max |q|, |k|, |v| of the call -> three words in the workspace (one 39 MB sweep, ~10 us)
+//   K 2^ek, V 2^ev     split by split_kv_f16_kernel; Q 2^eq (with the softmax scale folded in) split in registers
+//   S = acc 2^-(eq+ek) applied inside the exponential's fused multiply-add, no extra instruction
+//   P 2^14             the probabilities (<= 1) scaled to fp16's upper range before their split; the same factor is in
+//                      the running row sum, so it cancels in O / l, and 2^-ev is folded into the final normalisation.
+// e is chosen so the largest magnitude lands in [2^14, 2^15): no overflow, and elements down to 2^-18 of the maximum keep
+// their residual out of fp16's subnormals (below that the absolute error is under 2^-25 of the maximum).
+__device__ __forceinline__ int fp16_scale_exp(float amax) {
+    if (!(amax > 0.f)) return 0;
+    return max(-100, min(100, 14 - ilogbf(amax)));
+}
+
+__global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ q, const float *__restrict__ k,
+                                                     const float *__restrict__ v, long long rows, int row4,
+                                                     long long row_stride, unsigned *__restrict__ hdr) {
+    float mq = 0.f, mk = 0.f, mv = 0.f;
+    const long long total = rows * row4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long row = i / row4;
+        const size_t off = row * row_stride + (i - row * row4) * 4;
+        const float4 a = *reinterpret_cast<const float4 *>(q + off), b = *reinterpret_cast<const float4 *>(k + off);
+        const float4 c = *reinterpret_cast<const float4 *>(v + off);
+        mq = fmaxf(mq, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
+        mk = fmaxf(mk, fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w))));
+        mv = fmaxf(mv, fmaxf(fmaxf(fabsf(c.x), fabsf(c.y)), fmaxf(fabsf(c.z), fabsf(c.w))));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mq = fmaxf(mq, __shfl_xor(mq, o, 64)), mk = fmaxf(mk, __shfl_xor(mk, o, 64)), mv = fmaxf(mv, __shfl_xor(mv, o, 64));
+    }
+    __shared__ float wave_max[4][3];
+    if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6][0] = mq, wave_max[threadIdx.x >> 6][1] = mk, wave_max[threadIdx.x >> 6][2] = mv;
+    __syncthreads();
+    if (threadIdx.x < 3) {  // one atomic per block and tensor (same-address atomics serialise in L2: ~10 ns each);
+        const float m = fmaxf(fmaxf(wave_max[0][threadIdx.x], wave_max[1][threadIdx.x]),
+                              fmaxf(wave_max[2][threadIdx.x], wave_max[3][threadIdx.x]));
+        atomicMax(hdr + threadIdx.x, __float_as_uint(m));  // non-negative floats order like their bit patterns
+    }
+}
+
+// grid (key tiles of 64, H, B), 256 threads: as split_kv_kernel, two fp16 parts of K 2^ek and V 2^ev
+__global__ __launch_bounds__(256) void split_kv_f16_kernel(const float *__restrict__ k, const float *__restrict__ v, int S,
+                                                           int Spad, long long row_stride,
+                                                           const unsigned *__restrict__ hdr, _Float16 *__restrict__ Kp,
+                                                           _Float16 *__restrict__ Vt) {
+    __shared__ float vt[kD][kBN + 1];
+    const int tid = threadIdx.x, head = blockIdx.y, b = blockIdx.z, H = gridDim.y, B = gridDim.z;
+    const int key0 = blockIdx.x * kBN;
+    const size_t bh = (size_t)b * H + head, part_k = (size_t)B * H * S * kD, part_v = (size_t)B * H * kD * Spad;
+    const float sk = ldexpf(1.0f, fp16_scale_exp(__uint_as_float(hdr[1])));
+    const float sv = ldexpf(1.0f, fp16_scale_exp(__uint_as_float(hdr[2])));
+    const int key = tid >> 2, d0 = (tid & 3) * 16;
+    const bool live = key0 + key < S;
+    const size_t src = ((size_t)b * S + min(key0 + key, S - 1)) * row_stride + head * kD + d0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 kv = *reinterpret_cast<const float4 *>(k + src + 4 * q);
+        const float4 vv = *reinterpret_cast<const float4 *>(v + src + 4 * q);
+        const float kk[4] = {kv.x, kv.y, kv.z, kv.w};
+        f16x4 p1, p2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            _Float16 a, bb;
+            split2(kk[e] * sk, a, bb);
+            p1[e] = a, p2[e] = bb;
+        }
+        if (live) {
+            _Float16 *dst = Kp + (bh * S + key0 + key) * kD + d0 + 4 * q;
+            *reinterpret_cast<f16x4 *>(dst) = p1;
+            *reinterpret_cast<f16x4 *>(dst + part_k) = p2;
+        }
+        vt[d0 + 4 * q + 0][key] = live ? vv.x * sv : 0.f;
+        vt[d0 + 4 * q + 1][key] = live ? vv.y * sv : 0.f;
+        vt[d0 + 4 * q + 2][key] = live ? vv.z * sv : 0.f;
+        vt[d0 + 4 * q + 3][key] = live ? vv.w * sv : 0.f;
+    }
+    __syncthreads();
+    const int d = tid >> 2, kq = (tid & 3) * 16;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f16x4 p1, p2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            _Float16 a, bb;
+            split2(vt[d][kq + 4 * q + e], a, bb);
+            p1[e] = a, p2[e] = bb;
+        }
+        _Float16 *dst = Vt + (bh * kD + d) * Spad + key0 + kq + 4 * q;
+        *reinterpret_cast<f16x4 *>(dst) = p1;
+        *reinterpret_cast<f16x4 *>(dst + part_v) = p2;
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void selfattn_f16_kernel(const float *__restrict__ q, const _Float16 *__restrict__ Kp,
+                                                           const _Float16 *__restrict__ Vt, float *__restrict__ out,
+                                                           int S, int Spad, long long row_stride,
+                                                           long long out_row_stride, float scale_log2e, int nsplit,
+                                                           float *__restrict__ part, const unsigned *__restrict__ hdr,
+                                                           int H, int B, int q_tiles) {
+    __shared__ _Float16 Ks[2][kBN * kLdK];  // [part][key][d]
+    __shared__ _Float16 Vs[2][kD * kLdV];   // [part][d][key]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int r = lane & 31, hh = lane >> 5;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int slice = (j / q_tiles) * 8 + xcd;  // (batch, head, key-slice) index, XCD-aware as in selfattn_split_kernel
+    if (slice >= nsplit * H * B) return;
+    const int split = slice % nsplit, head = (slice / nsplit) % H, b = slice / (nsplit * H);
+    const int q0 = (j % q_tiles) * kBM + wave * 32;
+    const size_t bh = (size_t)b * H + head, part_k = (size_t)B * H * S * kD, part_v = (size_t)B * H * kD * Spad;
+    const int eq = fp16_scale_exp(__uint_as_float(hdr[0]) * scale_log2e);
+    const int ek = fp16_scale_exp(__uint_as_float(hdr[1])), ev = fp16_scale_exp(__uint_as_float(hdr[2]));
+    const float qs = scale_log2e * ldexpf(1.0f, eq);  // Q pre-scale (softmax scale and log2 e folded in)
+    const float cs = ldexpf(1.0f, -(eq + ek));        // raw accumulator -> log2-domain score
+
+    f16x8 Q1[4], Q2[4];
+    {
+        const float *qrow = q + ((size_t)b * S + min(q0 + r, S - 1)) * row_stride + head * kD;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float4 lo = *reinterpret_cast<const float4 *>(qrow + 16 * s + 8 * hh);
+            const float4 hi = *reinterpret_cast<const float4 *>(qrow + 16 * s + 8 * hh + 4);
+            const float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                _Float16 a, bb;
+                split2(x[jj] * qs, a, bb);
+                Q1[s][jj] = a, Q2[s][jj] = bb;
+            }
+        }
+    }
+    f32x16 O0, O1;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) O0[t] = 0.f, O1[t] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;
+
+    const int ntiles_all = (S + kBN - 1) / kBN;
+    const int kt_begin = (int)((long long)ntiles_all * split / nsplit);
+    const int ntiles = (int)((long long)ntiles_all * (split + 1) / nsplit);
+    const int srow0 = tid >> 3, sc8 = (tid & 7) * 8;  // 16-byte chunk tid + 256 i of a [64 rows][128 B] tile
+    uint4 ka0, ka1, kb0, kb1, va0, va1, vb0, vb1;     // the next tile's eight chunks, in flight under this tile's MFMAs
+#define AMAV_F16_LOAD(kt_)                                                                                         \
+    {                                                                                                              \
+        const int key0_ = (kt_) * kBN;                                                                             \
+        const size_t k0_ = (bh * S + min(key0_ + srow0, S - 1)) * kD + sc8;                                        \
+        const size_t k1_ = (bh * S + min(key0_ + srow0 + 32, S - 1)) * kD + sc8;                                   \
+        const size_t v0_ = (bh * kD + srow0) * Spad + key0_ + sc8, v1_ = v0_ + (size_t)32 * Spad;                  \
+        ka0 = *reinterpret_cast<const uint4 *>(Kp + k0_), ka1 = *reinterpret_cast<const uint4 *>(Kp + k1_);        \
+        kb0 = *reinterpret_cast<const uint4 *>(Kp + part_k + k0_), kb1 = *reinterpret_cast<const uint4 *>(Kp + part_k + k1_); \
+        va0 = *reinterpret_cast<const uint4 *>(Vt + v0_), va1 = *reinterpret_cast<const uint4 *>(Vt + v1_);        \
+        vb0 = *reinterpret_cast<const uint4 *>(Vt + part_v + v0_), vb1 = *reinterpret_cast<const uint4 *>(Vt + part_v + v1_); \
+    }
+#define AMAV_F16_STAGE(p_, i_, kr_, vr_)                                                             \
+    {                                                                                                \
+        *reinterpret_cast<uint4 *>(&Ks[p_][(srow0 + 32 * (i_)) * kLdK + sc8]) = kr_;                 \
+        uint2 *d_ = reinterpret_cast<uint2 *>(&Vs[p_][(srow0 + 32 * (i_)) * kLdV + sc8]); /* 136-byte rows: 8-byte aligned */ \
+        d_[0] = make_uint2(vr_.x, vr_.y), d_[1] = make_uint2(vr_.z, vr_.w);                          \
+    }
+    AMAV_F16_LOAD(kt_begin)
+    for (int kt = kt_begin; kt < ntiles; ++kt) {
+        const int key0 = kt * kBN;
+        AMAV_F16_STAGE(0, 0, ka0, va0) AMAV_F16_STAGE(0, 1, ka1, va1) AMAV_F16_STAGE(1, 0, kb0, vb0)
+        AMAV_F16_STAGE(1, 1, kb1, vb1)
+        __syncthreads();
+        if (kt + 1 < ntiles) AMAV_F16_LOAD(kt + 1)
+
+        // ---- raw S^T = K' Q'^T: three partial products per 16-wide k-step, small terms first
+        f32x16 S0, S1;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) S0[t] = 0.f, S1[t] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            f32x16 &Sx = kb ? S1 : S0;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int off = (r + 32 * kb) * kLdK + 16 * s + 8 * hh;
+                const f16x8 a1 = *reinterpret_cast<const f16x8 *>(&Ks[0][off]);
+                const f16x8 a2 = *reinterpret_cast<const f16x8 *>(&Ks[1][off]);
+                Sx = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, Q1[s], Sx, 0, 0, 0);
+                Sx = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, Q2[s], Sx, 0, 0, 0);
+                Sx = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, Q1[s], Sx, 0, 0, 0);
+            }
+        }
+        if ((kt + 1) * kBN > S) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int kk = key0 + (t & 3) + 8 * (t >> 2) + 4 * hh;
+                if (kk >= S) S0[t] = -INFINITY;
+                if (kk + 32 >= S) S1[t] = -INFINITY;
+            }
+        }
+        // ---- online softmax over this lane's query: the maximum of the raw scores, moved to the log2 domain once
+        float mx = S0[0];
+#pragma unroll
+        for (int t = 1; t < 16; ++t) mx = fmaxf(mx, S0[t]);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) mx = fmaxf(mx, S1[t]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx * cs);
+        const float corr = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) O0[t] *= corr, O1[t] *= corr;
+        const float shift = 14.0f - m_new;  // P' = 2^14 exp2(s - m)
+        float psum = 0.f;
+        // ---- O'^T += V'^T P'^T, software-pipelined: the exponentials and the split of step u + 1 between the six MFMAs
+        // of step u
+        auto parts = [&](int u, f16x8 &P1, f16x8 &P2) {
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const float raw = (u >> 1) ? S1[8 * (u & 1) + jj] : S0[8 * (u & 1) + jj];
+                const float pv = __builtin_amdgcn_exp2f(fmaf(raw, cs, shift));
+                psum += pv;
+                _Float16 a, bb;
+                split2(pv, a, bb);
+                P1[jj] = a, P2[jj] = bb;
+            }
+        };
+        f16x8 Pc1, Pc2, Pn1, Pn2;
+        parts(0, Pc1, Pc2);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {  // u = 2 kb + s2
+            const int kbase = 32 * (u >> 1) + 16 * (u & 1) + 4 * hh;
+            f16x8 vf[2][2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const _Float16 *src = &Vs[p][(r + 32 * a) * kLdV + kbase];
+                    const f16x4 lo = *reinterpret_cast<const f16x4 *>(src);
+                    const f16x4 hi = *reinterpret_cast<const f16x4 *>(src + 8);
+                    vf[a][p][0] = lo[0], vf[a][p][1] = lo[1], vf[a][p][2] = lo[2], vf[a][p][3] = lo[3];
+                    vf[a][p][4] = hi[0], vf[a][p][5] = hi[1], vf[a][p][6] = hi[2], vf[a][p][7] = hi[3];
+                }
+            if (u + 1 < 4) parts(u + 1, Pn1, Pn2);
+            O0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[0][1], Pc1, O0, 0, 0, 0);
+            O1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[1][1], Pc1, O1, 0, 0, 0);
+            O0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[0][0], Pc2, O0, 0, 0, 0);
+            O1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[1][0], Pc2, O1, 0, 0, 0);
+            O0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[0][0], Pc1, O0, 0, 0, 0);
+            O1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[1][0], Pc1, O1, 0, 0, 0);
+            if (u + 1 < 4) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);  // ten vector instructions of the next step
+                }
+                Pc1 = Pn1, Pc2 = Pn2;
+            }
+        }
+        l_run = l_run * corr + psum;
+        __syncthreads();
+    }
+#undef AMAV_F16_LOAD
+#undef AMAV_F16_STAGE
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);  // carries the 2^14 of P'
+    const float unv = ldexpf(1.0f, -ev);
+    if (nsplit > 1) {  // partial (O 2^14, m, l 2^14): the common factor cancels in combine_kernel
+        if (q0 + r < S) {
+            float *prow = part + ((((size_t)split * B + b) * H + head) * S + q0 + r) * (kD + 2);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = 8 * g + 4 * hh;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) prow[d + e] = O0[4 * g + e] * unv, prow[32 + d + e] = O1[4 * g + e] * unv;
+            }
+            if (hh == 0) prow[kD] = m_run, prow[kD + 1] = l_tot;
+        }
+        return;
+    }
+    const float inv = unv / l_tot;
+    if (q0 + r < S) {
+        float *orow = out + ((size_t)b * S + q0 + r) * out_row_stride + head * kD;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d = 8 * g + 4 * hh;
+            *reinterpret_cast<float4 *>(orow + d) =
+                make_float4(O0[4 * g] * inv, O0[4 * g + 1] * inv, O0[4 * g + 2] * inv, O0[4 * g + 3] * inv);
+            *reinterpret_cast<float4 *>(orow + 32 + d) =
+                make_float4(O1[4 * g] * inv, O1[4 * g + 1] * inv, O1[4 * g + 2] * inv, O1[4 * g + 3] * inv);
+        }
+    }
+}
+
 // Key-range split that best balances the (q-tile, head, batch) workgroups over the chip: a CU runs two workgroups
 // at a time (LDS / registers), so the kernel lasts ceil(blocks * s / CUs) slices of 1/s of the key sweep.
 static int choose_split(int B, int S, int H, int num_cus) {
@@ -549,14 +840,18 @@ static int attn_num_cus() {
     return n;
 }
 
-// AMAV_ATTN=f32 selects the fp32-MFMA kernel, anything else (default) the bf16 x 3 split kernel
-static bool attn_use_split() {
-    static const bool v = [] {
+// AMAV_ATTN=f32 selects the fp32-MFMA kernel, AMAV_ATTN=bf16 the bf16 x 3 split kernel, anything else (default) the
+// fp16 x 2 split kernel
+static int attn_variant() {  // 0: fp32 MFMA, 1: bf16 x 3, 2: fp16 x 2
+    static const int v = [] {
         const char *e = getenv("AMAV_ATTN");
-        return !(e && e[0] == 'f');
+        if (e && strcmp(e, "f32") == 0) return 0;
+        return e && strcmp(e, "bf16") == 0 ? 1 : 2;
     }();
     return v;
 }
+static bool attn_use_split() { return attn_variant() != 0; }
+constexpr size_t kAttnHeaderBytes = 256;  // fp16 variant: max |q|, |k|, |v| of the call
 
 static size_t attn_partial_bytes(int B, int S, int H, int ns) {
     return ns > 1 ? align_up((size_t)ns * B * H * S * (attn::kD + 2) * sizeof(float), 256) : 256;
@@ -567,8 +862,10 @@ extern "C" size_t amav_selfattn_workspace_bytes(int B, int S, int H, int D) {
     if (B <= 0 || S <= 0 || H <= 0 || D != attn::kD) return 0;
     const int ns = attn::choose_split(B, S, H, attn_num_cus());
     size_t need = attn_partial_bytes(B, S, H, ns);
-    if (attn_use_split())  // K parts [3][B H][S][64] + V^T parts [3][B H][64][S_pad], bf16
-        need += align_up(3 * (size_t)B * H * S * attn::kD * 2, 256) + align_up(3 * (size_t)B * H * attn::kD * attn_spad(S) * 2, 256);
+    const size_t parts = attn_variant() == 2 ? 2 : 3;
+    if (attn_use_split())  // [header] + K parts [parts][B H][S][64] + V^T parts [parts][B H][64][S_pad], 2-byte elements
+        need += kAttnHeaderBytes + align_up(parts * B * H * S * attn::kD * 2, 256) +
+                align_up(parts * B * H * attn::kD * attn_spad(S) * 2, 256);
     return need;
 }
 
@@ -595,14 +892,34 @@ extern "C" int amav_selfattn_forward(int B, int S, int H, int D, const float *q,
     if (split) {
         char *ws = static_cast<char *>(workspace);
         const int Spad = (int)attn_spad(S);
-        __bf16 *Kp = reinterpret_cast<__bf16 *>(ws + attn_partial_bytes(B, S, H, ns));
-        __bf16 *Vt = reinterpret_cast<__bf16 *>(reinterpret_cast<char *>(Kp) + align_up(3 * (size_t)B * H * S * attn::kD * 2, 256));
-        attn::split_kv_kernel<<<dim3((unsigned)(Spad / attn::kBN), H, B), 256, 0, stream>>>(k, v, S, Spad, row_stride, Kp, Vt);
+        const size_t parts = attn_variant() == 2 ? 2 : 3;
+        unsigned *hdr = reinterpret_cast<unsigned *>(ws + attn_partial_bytes(B, S, H, ns));
+        char *kp = reinterpret_cast<char *>(hdr) + kAttnHeaderBytes;
+        char *vt = kp + align_up(parts * B * H * S * attn::kD * 2, 256);
+        const dim3 kv_grid((unsigned)(Spad / attn::kBN), H, B);
         const int q_tiles = (S + attn::kBM - 1) / attn::kBM;
         const long long rounds = ((long long)ns * H * B + 7) / 8;  // 8 slices (one per XCD) per round
-        attn::selfattn_split_kernel<<<(unsigned)(rounds * 8 * q_tiles), 256, 0, stream>>>(
-            q, Kp, Vt, out, S, Spad, row_stride, out_row_stride, scale * 1.4426950408889634f, ns,
-            static_cast<float *>(workspace), H, B, q_tiles);
+        const unsigned main_grid = (unsigned)(rounds * 8 * q_tiles);
+        const float sl2 = scale * 1.4426950408889634f;
+        if (attn_variant() == 2) {
+            AMAV_REQUIRE(hipMemsetAsync(hdr, 0, 16, stream) == hipSuccess, "amav_selfattn_forward: header memset failed");
+            const long long rows = (long long)B * S;
+            const long long quads = rows * (H * attn::kD / 4);
+            attn::absmax_kernel<<<(unsigned)std::min<long long>((quads + 255) / 256, 512), 256, 0, stream>>>(
+                q, k, v, rows, H * attn::kD / 4, row_stride, hdr);
+            attn::split_kv_f16_kernel<<<kv_grid, 256, 0, stream>>>(k, v, S, Spad, row_stride, hdr,
+                                                                  reinterpret_cast<_Float16 *>(kp),
+                                                                  reinterpret_cast<_Float16 *>(vt));
+            attn::selfattn_f16_kernel<<<main_grid, 256, 0, stream>>>(
+                q, reinterpret_cast<const _Float16 *>(kp), reinterpret_cast<const _Float16 *>(vt), out, S, Spad,
+                row_stride, out_row_stride, sl2, ns, static_cast<float *>(workspace), hdr, H, B, q_tiles);
+        } else {
+            attn::split_kv_kernel<<<kv_grid, 256, 0, stream>>>(k, v, S, Spad, row_stride, reinterpret_cast<__bf16 *>(kp),
+                                                              reinterpret_cast<__bf16 *>(vt));
+            attn::selfattn_split_kernel<<<main_grid, 256, 0, stream>>>(
+                q, reinterpret_cast<const __bf16 *>(kp), reinterpret_cast<const __bf16 *>(vt), out, S, Spad, row_stride,
+                out_row_stride, sl2, ns, static_cast<float *>(workspace), H, B, q_tiles);
+        }
     } else
         attn::selfattn_kernel<<<grid, 256, 0, stream>>>(q, k, v, out, S, row_stride, out_row_stride,
                                                         scale * 1.4426950408889634f, ns, static_cast<float *>(workspace));
