@@ -616,7 +616,7 @@ __global__ __launch_bounds__(256) void split_kv_f16_kernel(const float *__restri
     }
 }
 
-__global__ __launch_bounds__(256, 2) void selfattn_f16_kernel(const float *__restrict__ q, const _Float16 *__restrict__ Kp,
+__global__ __launch_bounds__(256, 3) void selfattn_f16_kernel(const float *__restrict__ q, const _Float16 *__restrict__ Kp,
                                                            const _Float16 *__restrict__ Vt, float *__restrict__ out,
                                                            int S, int Spad, long long row_stride,
                                                            long long out_row_stride, float scale_log2e, int nsplit,
