@@ -249,7 +249,7 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 // by pre-scaling x with a power of two (exact) so that the tensor's bound sits just under fp16's maximum.
 __device__ __forceinline__ void split2(float x, _Float16 &a, _Float16 &b) {
     a = (_Float16)x;
-    b = (_Float16)(x - (float)a);
+    b = (_Float16)__builtin_fmaf((float)a, -1.0f, x);  // x - a, exact; written as an fma so it can be one mixed-precision op
 }
 
 __device__ __forceinline__ void split3(float x, __bf16 &a, __bf16 &b, __bf16 &c) {
@@ -722,9 +722,11 @@ __global__ __launch_bounds__(256, 3) void selfattn_f16_kernel(const float *__res
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx * cs);
         const float corr = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
+        if (__any(m_new != m_run)) {  // wave-uniform: after the first tiles the running maxima rarely move
 #pragma unroll
-        for (int t = 0; t < 16; ++t) O0[t] *= corr, O1[t] *= corr;
+            for (int t = 0; t < 16; ++t) O0[t] *= corr, O1[t] *= corr;
+        }
+        m_run = m_new;
         const float shift = 14.0f - m_new;  // P' = 2^14 exp2(s - m)
         float psum = 0.f;
         // ---- O'^T += V'^T P'^T, software-pipelined: the exponentials and the split of step u + 1 between the six MFMAs

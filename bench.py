@@ -19,7 +19,7 @@ own stream), `cpu_baseline` (the CPU oracle = a port, timed on this box's host c
 same workload), `parity` (GPU vs oracle on that sample; all-pixel maxima and counts, and a `pass` flag: the process
 exits non-zero after printing the line when it is false) and -- default workload at N = 1 only -- `full_path`: a few
 250-frame steps of BASELINE configs[2] (the audio-driven path the >= 30 frames/s/GPU target is quoted on) run after
-the timed region, with their own `roofline` (fp32 MFMA self-attention, HIP events around every launch),
+the timed region, with their own `roofline` (the self-attention kernel, HIP events around every launch),
 `cpu_baseline` and `parity` (tokens and frames after two autoregressive steps against the oracle), and `point_refiner`:
 the PTv3 point refiner the reference's default renderer runs on the same frames, with the roofline
 of its dominant kernel, the CPU oracle's time for one frame and the parity of the refined points.
@@ -148,8 +148,11 @@ def build_renderer(args, device, with_decoder=False):
     return init_random_heads(Renderer(cfg, smpl_decoder=dec).eval()), cfg
 
 
+# fp32 tensors end to end; the transformer's matrix products are fp32-equivalent sums of fp16 partial products with
+# fp32 accumulation, everything else plain fp32
+TRANSFORMER_DTYPE = "f32 (transformer products: fp16 x 2 split operands, fp32 accumulate)"
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA = the fp32 vector peak
-MFMA_BF16_PEAK_TFLOPS = 2516.6  # dense bf16 MFMA: 32x32x16 in 32 cycles/SIMD, 1024 SIMDs, 2.4 GHz
+MFMA_16BIT_PEAK_TFLOPS = 2516.6  # dense bf16 / fp16 MFMA: 32x32x16 in 32 cycles per SIMD, 1024 SIMDs, 2.4 GHz
 
 
 class FullPath:
@@ -247,27 +250,34 @@ class FullPath:
         # one AR step: L x (q/k/v + out projections 4 * 2 S 512^2, GEGLU feed-forward 2 S 512 (4096 + 2048), attention)
         # + proj_in / proj_out 2 * 2 S 256 512
         step_flop = L * (flop + 2.0 * S * 512 * (4 * 512 + 4096 + 2048)) + 4.0 * S * 256 * 512
-        split = os.environ.get("AMAV_ATTN", "split") != "f32"
+        variant = os.environ.get("AMAV_ATTN", "fp16")
         tf = flop / (ms * 1e-3) / 1e12
-        out = {"bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-               "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": ms,
-               "algorithmic_flop_per_launch": flop, "launches_timed": len(events),
-               "transformer_step": {"ms": step_ms, "flop": step_flop, "achieved": step_flop / (step_ms * 1e-3) / 1e12,
-                                    "frac": step_flop / (step_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS}}
-        if split:
-            # The product is fp32 in, fp32-equivalent out (1.6e-7 max abs against fp64, tools/attention_accuracy.py), so
-            # `achieved` / `peak` are the algorithmic fp32 FLOP against the fp32 MFMA peak, as for the fp32 kernel.  The
-            # arithmetic itself runs as six bf16 partial products per fp32 product on the bf16 matrix pipe: `pipe` prices
-            # the FLOP actually issued against THAT pipe's dense peak -- the figure that says how well the kernel uses
-            # the hardware it runs on.
-            out["kernel"] = ("split_kv_kernel + selfattn_split_kernel + combine_kernel (flash attention, bf16x3 split "
-                             "operands on the bf16 MFMA pipe, fp32-equivalent result, S=%d, H=%d)" % (S, H))
-            out["pipe"] = {"dtype": "bf16", "issued_flop_per_launch": 6.0 * flop, "achieved": 6.0 * tf,
-                           "peak": MFMA_BF16_PEAK_TFLOPS, "frac": 6.0 * tf / MFMA_BF16_PEAK_TFLOPS,
-                           "mfma_busy_frac": pmc_mfma_busy("selfattn_split_kernel")}
-        else:
-            out["kernel"] = "selfattn_kernel + combine_kernel (fp32 MFMA flash attention, S=%d, H=%d)" % (S, H)
-            out["mfma_busy_frac"] = pmc_mfma_busy("selfattn_kernel")
+        step_tf = step_flop / (step_ms * 1e-3) / 1e12
+        out = {"bound": "mfma", "unit": "TFLOP/s", "traffic": None, "avg_launch_ms": ms,
+               "algorithmic_flop_per_launch": flop, "launches_timed": len(events)}
+        if variant == "f32":
+            out.update({"kernel": "selfattn_kernel + combine_kernel (fp32 MFMA flash attention, S=%d, H=%d)" % (S, H),
+                        "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "frac": tf / MFMA_F32_PEAK_TFLOPS,
+                        "mfma_busy_frac": pmc_mfma_busy("selfattn_kernel"),
+                        "transformer_step": {"ms": step_ms, "flop": step_flop, "achieved": step_tf,
+                                             "frac": step_tf / MFMA_F32_PEAK_TFLOPS}})
+            return out
+        # fp32 in, fp32-equivalent out (1.1e-7 max abs against fp64 at the reference shape, tools/attention_accuracy.py;
+        # the library's fp32 SDPA: 4.8e-7), computed as `products` low-precision partial products per fp32 product on the
+        # 16-bit matrix pipe.  `achieved` / `frac` price the FLOP actually ISSUED against THAT pipe's dense peak -- the
+        # figure that says how well the kernel uses the hardware it runs on; `fp32_equivalent` is the algorithmic rate,
+        # next to the fp32 MFMA peak it no longer is bounded by.
+        products, kname, parts = (6, "selfattn_split_kernel", "bf16 x 3") if variant == "bf16" else (3, "selfattn_f16_kernel", "fp16 x 2")
+        out.update({"kernel": "operand split + %s + combine_kernel (flash attention on %s split operands, %d partial "
+                              "products per fp32 product, fp32-equivalent result, S=%d, H=%d)" % (kname, parts, products, S, H),
+                    "issued_flop_per_launch": products * flop, "achieved": products * tf, "peak": MFMA_16BIT_PEAK_TFLOPS,
+                    "frac": products * tf / MFMA_16BIT_PEAK_TFLOPS, "mfma_busy_frac": pmc_mfma_busy(kname),
+                    "fp32_equivalent": {"achieved": tf, "fp32_mfma_peak": MFMA_F32_PEAK_TFLOPS,
+                                        "ratio_to_fp32_mfma_peak": tf / MFMA_F32_PEAK_TFLOPS},
+                    "transformer_step": {"ms": step_ms, "flop": step_flop, "achieved_fp32_equivalent": step_tf,
+                                         "ratio_to_fp32_mfma_peak": step_tf / MFMA_F32_PEAK_TFLOPS,
+                                         "note": "projections as fp16 x 2 split GEMMs (3 partial products), attention as "
+                                                 "above; proj_in / proj_out and the small cross-attention rows in fp32"}})
         return out
 
     def cpu_baseline_and_parity(self, ar_steps=2):
@@ -429,7 +439,7 @@ def measure_full_path(args, device, rank, steps, warmup, with_cpu):
            "metric": "rendered frames/sec, audio-driven path", "value": fp.F * steps / elapsed, "unit": "frames/s",
            "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "frames_per_step": fp.F,
            "ms_per_frame": elapsed / steps / fp.F * 1e3, "target_frames_per_s_per_gpu": 30.0,
-           "output_finite": bool(torch.isfinite(rgba).all()),
+           "dtype": TRANSFORMER_DTYPE, "output_finite": bool(torch.isfinite(rgba).all()),
            "coverage": float((rgba[..., 3] > 0.5).float().mean()),
            "weights": "random init (transformer.proj_out scaled by 0.02 so the AR chain stays bounded)",
            "roofline": fp.attention_roofline()}
@@ -490,7 +500,7 @@ def run_full_workload(args, device, world, rank, dist):
                   "decode -> rasterize)",
         "value": world * F * args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": TRANSFORMER_DTYPE, "data": "synthetic",
         "config": {"workload": "BASELINE configs[2]: synthetic 16 kHz audio -> Wav2Vec2 (random weights) -> "
                                f"AudioTriplaneNet (8 layers, S=6304, {fp.windows} chained windows of {fp.T} steps) -> "
                                "SMPLXDecoder -> LBS -> decode -> rasterize 250 x 512x512",
