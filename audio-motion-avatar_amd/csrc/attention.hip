@@ -523,13 +523,18 @@ __global__ __launch_bounds__(256, 2) void selfattn_split_kernel(const float *__r
 // fp16 x 2 form of the split kernel: x 2^e = h1 + h2 with fp16 parts carries 22 bits, and a product needs THREE partial
 // products (h1 g1, h1 g2, h2 g1) instead of six -- half the MFMA work and two thirds of the LDS traffic.  fp16 has five
 // exponent bits, so every operand is pre-scaled by a power of two (exact) taken from its measured magnitude:
-//   absmax_kernel      max |q|, |k|, |v| of the call -> three words in the workspace (one 39 MB sweep, ~10 us)
+//   absmax_kernel      max |q|, |k|, |v| of the call -> three words in the workspace (one 39 MB sweep, ~12 us), unless
+//                      the caller hands over bounds it can prove (amav_selfattn_forward_bounded)
 //   K 2^ek, V 2^ev     split by split_kv_f16_kernel; Q 2^eq (with the softmax scale folded in) split in registers
 //   S = acc 2^-(eq+ek) applied inside the exponential's fused multiply-add, no extra instruction
 //   P 2^14             the probabilities (<= 1) scaled to fp16's upper range before their split; the same factor is in
 //                      the running row sum, so it cancels in O / l, and 2^-ev is folded into the final normalisation.
 // e is chosen so the largest magnitude lands in [2^14, 2^15): no overflow, and elements down to 2^-18 of the maximum keep
 // their residual out of fp16's subnormals (below that the absolute error is under 2^-25 of the maximum).
+struct Magnitudes {  // upper bounds of |q|, |k|, |v| handed over by the caller (instead of the measured maxima)
+    float q, k, v;
+};
+
 __device__ __forceinline__ int fp16_scale_exp(float amax) {
     if (!(amax > 0.f)) return 0;
     return max(-100, min(100, 14 - ilogbf(amax)));
@@ -566,14 +571,14 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ q
 // grid (key tiles of 64, H, B), 256 threads: as split_kv_kernel, two fp16 parts of K 2^ek and V 2^ev
 __global__ __launch_bounds__(256) void split_kv_f16_kernel(const float *__restrict__ k, const float *__restrict__ v, int S,
                                                            int Spad, long long row_stride,
-                                                           const unsigned *__restrict__ hdr, _Float16 *__restrict__ Kp,
-                                                           _Float16 *__restrict__ Vt) {
+                                                           const unsigned *__restrict__ hdr, Magnitudes given,
+                                                           _Float16 *__restrict__ Kp, _Float16 *__restrict__ Vt) {
     __shared__ float vt[kD][kBN + 1];
     const int tid = threadIdx.x, head = blockIdx.y, b = blockIdx.z, H = gridDim.y, B = gridDim.z;
     const int key0 = blockIdx.x * kBN;
     const size_t bh = (size_t)b * H + head, part_k = (size_t)B * H * S * kD, part_v = (size_t)B * H * kD * Spad;
-    const float sk = ldexpf(1.0f, fp16_scale_exp(__uint_as_float(hdr[1])));
-    const float sv = ldexpf(1.0f, fp16_scale_exp(__uint_as_float(hdr[2])));
+    const float sk = ldexpf(1.0f, fp16_scale_exp(hdr ? __uint_as_float(hdr[1]) : given.k));
+    const float sv = ldexpf(1.0f, fp16_scale_exp(hdr ? __uint_as_float(hdr[2]) : given.v));
     const int key = tid >> 2, d0 = (tid & 3) * 16;
     const bool live = key0 + key < S;
     const size_t src = ((size_t)b * S + min(key0 + key, S - 1)) * row_stride + head * kD + d0;
@@ -621,7 +626,7 @@ __global__ __launch_bounds__(256, 3) void selfattn_f16_kernel(const float *__res
                                                            int S, int Spad, long long row_stride,
                                                            long long out_row_stride, float scale_log2e, int nsplit,
                                                            float *__restrict__ part, const unsigned *__restrict__ hdr,
-                                                           int H, int B, int q_tiles) {
+                                                           Magnitudes given, int H, int B, int q_tiles) {
     __shared__ _Float16 Ks[2][kBN * kLdK];  // [part][key][d]
     __shared__ _Float16 Vs[2][kD * kLdV];   // [part][d][key]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -632,8 +637,9 @@ __global__ __launch_bounds__(256, 3) void selfattn_f16_kernel(const float *__res
     const int split = slice % nsplit, head = (slice / nsplit) % H, b = slice / (nsplit * H);
     const int q0 = (j % q_tiles) * kBM + wave * 32;
     const size_t bh = (size_t)b * H + head, part_k = (size_t)B * H * S * kD, part_v = (size_t)B * H * kD * Spad;
-    const int eq = fp16_scale_exp(__uint_as_float(hdr[0]) * scale_log2e);
-    const int ek = fp16_scale_exp(__uint_as_float(hdr[1])), ev = fp16_scale_exp(__uint_as_float(hdr[2]));
+    const int eq = fp16_scale_exp((hdr ? __uint_as_float(hdr[0]) : given.q) * scale_log2e);
+    const int ek = fp16_scale_exp(hdr ? __uint_as_float(hdr[1]) : given.k);
+    const int ev = fp16_scale_exp(hdr ? __uint_as_float(hdr[2]) : given.v);
     const float qs = scale_log2e * ldexpf(1.0f, eq);  // Q pre-scale (softmax scale and log2 e folded in)
     const float cs = ldexpf(1.0f, -(eq + ek));        // raw accumulator -> log2-domain score
 
@@ -874,6 +880,19 @@ extern "C" size_t amav_selfattn_workspace_bytes(int B, int S, int H, int D) {
 extern "C" int amav_selfattn_forward(int B, int S, int H, int D, const float *q, const float *k, const float *v,
                                      int64_t row_stride, float *out, int64_t out_row_stride, float scale,
                                      void *workspace, size_t workspace_bytes, void *stream_) {
+    return amav_selfattn_forward_bounded(B, S, H, D, q, k, v, row_stride, out, out_row_stride, scale, 0.f, 0.f, 0.f,
+                                         workspace, workspace_bytes, stream_);
+}
+
+extern "C" int amav_selfattn_forward_bounded(int B, int S, int H, int D, const float *q, const float *k, const float *v,
+                                             int64_t row_stride, float *out, int64_t out_row_stride, float scale,
+                                             float q_bound, float k_bound, float v_bound, void *workspace,
+                                             size_t workspace_bytes, void *stream_) {
+    const bool bounded = q_bound > 0.f && k_bound > 0.f && v_bound > 0.f;
+    AMAV_REQUIRE(bounded || (q_bound == 0.f && k_bound == 0.f && v_bound == 0.f),
+                 "amav_selfattn_forward_bounded: give all three bounds (> 0, finite) or none (0)");
+    AMAV_REQUIRE(std::isfinite(q_bound) && std::isfinite(k_bound) && std::isfinite(v_bound),
+                 "amav_selfattn_forward_bounded: bounds must be finite");
     AMAV_REQUIRE(B > 0 && S > 0 && H > 0, "amav_selfattn_forward: bad sizes B=%d S=%d H=%d", B, S, H);
     AMAV_REQUIRE(D == attn::kD, "amav_selfattn_forward: head_dim %d (only %d is built)", D, attn::kD);
     AMAV_REQUIRE(q && k && v && out, "amav_selfattn_forward: NULL pointer");
@@ -904,17 +923,22 @@ extern "C" int amav_selfattn_forward(int B, int S, int H, int D, const float *q,
         const unsigned main_grid = (unsigned)(rounds * 8 * q_tiles);
         const float sl2 = scale * 1.4426950408889634f;
         if (attn_variant() == 2) {
-            AMAV_REQUIRE(hipMemsetAsync(hdr, 0, 16, stream) == hipSuccess, "amav_selfattn_forward: header memset failed");
-            const long long rows = (long long)B * S;
-            const long long quads = rows * (H * attn::kD / 4);
-            attn::absmax_kernel<<<(unsigned)std::min<long long>((quads + 255) / 256, 512), 256, 0, stream>>>(
-                q, k, v, rows, H * attn::kD / 4, row_stride, hdr);
-            attn::split_kv_f16_kernel<<<kv_grid, 256, 0, stream>>>(k, v, S, Spad, row_stride, hdr,
+            const attn::Magnitudes given = {q_bound, k_bound, v_bound};
+            if (bounded) {
+                hdr = nullptr;  // the kernels scale from `given`
+            } else {            // measure max |q|, |k|, |v|
+                AMAV_REQUIRE(hipMemsetAsync(hdr, 0, 16, stream) == hipSuccess, "amav_selfattn_forward: header memset failed");
+                const long long rows = (long long)B * S;
+                const long long quads = rows * (H * attn::kD / 4);
+                attn::absmax_kernel<<<(unsigned)std::min<long long>((quads + 255) / 256, 512), 256, 0, stream>>>(
+                    q, k, v, rows, H * attn::kD / 4, row_stride, hdr);
+            }
+            attn::split_kv_f16_kernel<<<kv_grid, 256, 0, stream>>>(k, v, S, Spad, row_stride, hdr, given,
                                                                   reinterpret_cast<_Float16 *>(kp),
                                                                   reinterpret_cast<_Float16 *>(vt));
             attn::selfattn_f16_kernel<<<main_grid, 256, 0, stream>>>(
                 q, reinterpret_cast<const _Float16 *>(kp), reinterpret_cast<const _Float16 *>(vt), out, S, Spad,
-                row_stride, out_row_stride, sl2, ns, static_cast<float *>(workspace), hdr, H, B, q_tiles);
+                row_stride, out_row_stride, sl2, ns, static_cast<float *>(workspace), hdr, given, H, B, q_tiles);
         } else {
             attn::split_kv_kernel<<<kv_grid, 256, 0, stream>>>(k, v, S, Spad, row_stride, reinterpret_cast<__bf16 *>(kp),
                                                               reinterpret_cast<__bf16 *>(vt));

@@ -531,8 +531,10 @@ def points_project(points, w2c, intrinsics, features, radius_px):
 ATTN_PROFILE_EVENTS = None
 
 
-def selfattn(q, k, v, heads, scale=None):
-    """softmax(q k^T * scale) v for [B,S,H*D] fp32 tensors (row stride may exceed H*D), D = 64."""
+def selfattn(q, k, v, heads, scale=None, bounds=None):
+    """softmax(q k^T * scale) v for [B,S,H*D] fp32 tensors (row stride may exceed H*D), D = 64.  bounds: (|q|, |k|, |v|)
+    upper bounds the caller can prove, which spare the kernel its magnitude pre-pass (include/amav.h,
+    amav_selfattn_forward_bounded); None: measured."""
     for name, t in (("q", q), ("k", k), ("v", v)):
         _need(t, name)
         if t.dim() != 3 or t.stride(2) != 1 or t.stride(0) != t.shape[1] * t.stride(1):
@@ -549,9 +551,11 @@ def selfattn(q, k, v, heads, scale=None):
     ev = ATTN_PROFILE_EVENTS.pop(0) if ATTN_PROFILE_EVENTS else None
     if ev is not None:
         ev[0].record()
-    check(_lib.lib().amav_selfattn_forward(B, S, heads, D, q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(1),
-                                           out.data_ptr(), HD, float(scale if scale is not None else D ** -0.5),
-                                           ws.data_ptr(), nbytes, _stream()), "amav_selfattn_forward")
+    qb, kb, vb = (float(x) for x in bounds) if bounds is not None else (0.0, 0.0, 0.0)
+    check(_lib.lib().amav_selfattn_forward_bounded(B, S, heads, D, q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(1),
+                                                   out.data_ptr(), HD, float(scale if scale is not None else D ** -0.5),
+                                                   qb, kb, vb, ws.data_ptr(), nbytes, _stream()),
+          "amav_selfattn_forward_bounded")
     if ev is not None:
         ev[1].record()
     return out

@@ -145,12 +145,13 @@ class Attention(nn.Module):
             self._qkv = (version, torch.cat([w.detach() for w in ws], dim=0).contiguous())
         return self._qkv[1]
 
-    def attend(self, qkv, out_bias=True, out_exp=None):
+    def attend(self, qkv, out_bias=True, out_exp=None, bounds=None):
         """qkv [B,S,3*inner] (the fused projection's output, read in place) -> to_out(softmax(q k^T / sqrt(d)) v);
         out_bias=False leaves to_out's bias to the caller (forward_fused adds it in its next pass); out_exp: the scale
-        exponent of the attention output's proven bound, which sends to_out through the fp16 x 2 GEMM."""
+        exponent of the attention output's proven bound, which sends to_out through the fp16 x 2 GEMM; bounds: proven
+        (|q|, |k|, |v|) bounds for the kernel's operand scaling."""
         i = self.inner_dim
-        out = ops.selfattn(qkv[..., :i], qkv[..., i:2 * i], qkv[..., 2 * i:], self.heads)
+        out = ops.selfattn(qkv[..., :i], qkv[..., i:2 * i], qkv[..., 2 * i:], self.heads, bounds=bounds)
         if out_exp is None:
             return linear(out, self.to_out[0].weight, self.to_out[0].bias if out_bias else None)
         a = ops.split_operand(out.view(-1, i), fmt=ops.SPLIT_FP16X2, scale_exp=out_exp)
@@ -233,11 +234,11 @@ class BasicTransformerBlock(nn.Module):
             # every projection as an fp16 x 2 split GEMM: each pass writes its rows as the split operand of the GEMM that
             # follows, pre-scaled from the proven bounds of _fp16_plan, and the projections' biases are added by the
             # pass that reads their output
-            e_n1, e_attn, e_n3, e_ff = self._fp16_plan()
+            e_n1, e_attn, e_n3, e_ff, qkv_bounds = self._fp16_plan()
             h, n1 = ops.add_layernorm(h, pending, None, self.norm1.weight, self.norm1.bias, self.norm1.eps,
                                       add_bias=pending_bias, split=ops.SPLIT_FP16X2, split_exp=e_n1)
             qkv = gemm_fp16(n1, e_n1, self.attn1._qkv_weight()).view(B, S, -1)
-            a1 = self.attn1.attend(qkv, out_bias=False, out_exp=e_attn)
+            a1 = self.attn1.attend(qkv, out_bias=False, out_exp=e_attn, bounds=qkv_bounds)
             h, n3 = ops.add_layernorm(h, a1, row, self.norm3.weight, self.norm3.bias, self.norm3.eps,
                                       add_bias=self.attn1.to_out[0].bias, split=ops.SPLIT_FP16X2, split_exp=e_n3)
             gated = ops.geglu(gemm_fp16(n3, e_n3, ff_in.weight), bias=ff_in.bias, split_exp=e_ff)
@@ -263,8 +264,8 @@ class BasicTransformerBlock(nn.Module):
         return h, (self.ff(n3), None)
 
     def _fp16_plan(self):
-        """Scale exponents (e_n1, e_attn, e_n3, e_ff) of the four activation operands of forward_fused, each from a bound
-        that holds for EVERY input:
+        """Scale exponents (e_n1, e_attn, e_n3, e_ff) of the four activation operands of forward_fused and the (|q|, |k|,
+        |v|) bounds of the attention kernel's operands, each from a bound that holds for EVERY input:
           LayerNorm rows n = z w + b with |z_i| <= sqrt(dim) and ||z||_2 <= sqrt(dim):
               |n_i| <= sqrt(dim) max|w| + max|b|,      ||n||_2 <= sqrt(dim) max|w| + ||b||_2
           a projection of such a row: |W_j n (+ c_j)| <= max_j ||W_j||_2 ||n||_2 (+ max|c|)        (Cauchy-Schwarz)
@@ -273,8 +274,8 @@ class BasicTransformerBlock(nn.Module):
         The bounds overshoot typical magnitudes by 2^4..2^9; fp16 keeps a value's residual exact down to 2^-18 of the
         scaled bound, so the headroom only costs precision on elements that are already negligible."""
         ff_in = self.ff.net[0].proj
-        tensors = (self.norm1.weight, self.norm1.bias, self.norm3.weight, self.norm3.bias, self.attn1.to_v.weight,
-                   ff_in.weight, ff_in.bias)
+        tensors = (self.norm1.weight, self.norm1.bias, self.norm3.weight, self.norm3.bias, self.attn1.to_q.weight,
+                   self.attn1.to_k.weight, self.attn1.to_v.weight, ff_in.weight, ff_in.bias)
 
         def make():
             dim = self.norm1.weight.numel()
@@ -282,15 +283,17 @@ class BasicTransformerBlock(nn.Module):
             stats = torch.stack([
                 self.norm1.weight.abs().max(), self.norm1.bias.abs().max(), self.norm1.bias.norm(),
                 self.norm3.weight.abs().max(), self.norm3.bias.abs().max(), self.norm3.bias.norm(),
-                self.attn1.to_v.weight.norm(dim=1).max(),
+                self.attn1.to_v.weight.norm(dim=1).max(), self.attn1.to_q.weight.norm(dim=1).max(),
+                self.attn1.to_k.weight.norm(dim=1).max(),
                 ff_in.weight[:inner].norm(dim=1).max(), ff_in.weight[inner:].norm(dim=1).max(),
                 ff_in.bias[:inner].abs().max(), ff_in.bias[inner:].abs().max()]).double().tolist()  # one host sync
-            w1, b1, b1_l2, w3, b3, b3_l2, v_rows, h_rows, g_rows, h_bias, g_bias = stats
+            w1, b1, b1_l2, w3, b3, b3_l2, v_rows, q_rows, k_rows, h_rows, g_rows, h_bias, g_bias = stats
             root = math.sqrt(dim)
             n1_l2, n3_l2 = root * w1 + b1_l2, root * w3 + b3_l2
             v_bound = v_rows * n1_l2 + (self.attn1.to_v.bias.abs().max().item() if self.attn1.to_v.bias is not None else 0.0)
             ff_bound = (h_rows * n3_l2 + h_bias) * (g_rows * n3_l2 + g_bias)
-            return tuple(_scale_exp(b) for b in (root * w1 + b1, v_bound, root * w3 + b3, ff_bound))
+            exps = tuple(_scale_exp(b) for b in (root * w1 + b1, v_bound, root * w3 + b3, ff_bound))
+            return exps + ((q_rows * n1_l2, k_rows * n1_l2, v_bound),)  # attention_bias=False: no q / k bias
 
         return _memo("fp16_plan", tensors, make)
 

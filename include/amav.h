@@ -259,15 +259,27 @@ int amav_points_project(int batch, int num_points, int channels, int height, int
 
 /* ------------------------------------------------------------------------------------------------------------
  * Self-attention of the audio transformer (diffusers Attention -> F.scaled_dot_product_attention as reached from
- * src/models/transformers.py:329-336): softmax(Q K^T * scale) V, fp32 in/out, no mask, on MFMA
- * (v_mfma_f32_32x32x2_f32, exact fp32 products).  q,k,v,out: [B, S, H*D] with row stride `row_stride` floats
- * (so a fused QKV projection output can be passed without a copy); D must be 64.  The key sweep may be split over
- * several workgroups for load balance; their partial softmax states live in the caller's workspace.
+ * src/models/transformers.py:329-336): softmax(Q K^T * scale) V, fp32 in/out, no mask.  q,k,v,out: [B, S, H*D] with
+ * row stride `row_stride` floats (so a fused QKV projection output can be passed without a copy); D must be 64.  The key
+ * sweep may be split over several workgroups for load balance; their partial softmax states and the split K / V
+ * operands live in the caller's workspace.
+ *
+ * The products are fp32-equivalent sums of low-precision partial products on the 16-bit MFMA pipe (1.1e-7 max abs
+ * against fp64 at the reference shape; the library's fp32 SDPA: 4.8e-7): by default two fp16 parts per operand, three
+ * partial products, every operand pre-scaled by a power of two taken from its magnitude -- measured by a pre-pass over
+ * q, k, v (amav_selfattn_forward), or handed over by a caller that can PROVE upper bounds of |q|, |k|, |v|
+ * (amav_selfattn_forward_bounded with all three > 0; a bound the data exceeds by more than 2x overflows fp16).  The
+ * process-wide switch AMAV_ATTN=bf16 selects three bf16 parts / six partial products (no scaling involved),
+ * AMAV_ATTN=f32 the exact-product fp32 MFMA kernel (v_mfma_f32_32x32x2_f32).
  */
 size_t amav_selfattn_workspace_bytes(int batch, int seq_len, int heads, int head_dim);
 int amav_selfattn_forward(int batch, int seq_len, int heads, int head_dim, const float *q_dev, const float *k_dev,
                           const float *v_dev, int64_t row_stride, float *out_dev, int64_t out_row_stride,
                           float scale, void *workspace, size_t workspace_bytes, void *stream);
+int amav_selfattn_forward_bounded(int batch, int seq_len, int heads, int head_dim, const float *q_dev,
+                                  const float *k_dev, const float *v_dev, int64_t row_stride, float *out_dev,
+                                  int64_t out_row_stride, float scale, float q_bound, float k_bound, float v_bound,
+                                  void *workspace, size_t workspace_bytes, void *stream);
 
 /* Operand of an fp32-equivalent nn.Linear (src/models/transformers.py:70-84, 448, 505: the to_q/k/v, to_out and
  * feed-forward projections) computed as ONE low-precision GEMM with fp32 accumulation over operands split into parts

@@ -93,3 +93,27 @@ def test_fused_residual_adds_and_layernorm(dim):
     assert (n.double() - want_n).abs().max().item() <= 5e-6
     h2, n2 = ops.add_layernorm(h, None, None, w, b, 1e-5)
     assert torch.equal(h2, h) and (n2.double() - F.layer_norm(h.double(), (dim,), w.double(), b.double(), 1e-5)).abs().max() <= 5e-6
+
+
+@pytest.mark.parametrize("slack", [1.0, 40.0])
+def test_selfattn_with_caller_bounds_matches_the_measured_scaling(slack):
+    from audio_motion_avatar_amd import ops
+
+    g = torch.Generator().manual_seed(77)
+    B, S, H = 1, 700, 4
+    q, k, v = (torch.randn(B, S, H * 64, generator=g) * s for s in (3.0, 0.02, 50.0))  # very different magnitudes
+    bounds = tuple(t.abs().max().item() * slack for t in (q, k, v))
+    out = ops.selfattn(q.cuda(), k.cuda(), v.cuda(), H, bounds=bounds).cpu()
+    ref = reference(q, k, v, H)
+    assert (out.double() - ref).abs().max() <= 2e-5 * 50.0
+    measured = ops.selfattn(q.cuda(), k.cuda(), v.cuda(), H).cpu()
+    assert (out - measured).abs().max() <= 1e-5 * 50.0
+
+
+def test_selfattn_rejects_partial_bounds():
+    from audio_motion_avatar_amd import ops
+    from audio_motion_avatar_amd._lib import AmavError
+
+    x = torch.randn(1, 64, 64).cuda()
+    with pytest.raises(AmavError):
+        ops.selfattn(x, x, x, 1, bounds=(1.0, 0.0, 1.0))

@@ -182,7 +182,7 @@ def test_fp16_plan_bounds_hold_and_follow_weight_updates():
     blk = BasicTransformerBlock(512, 8, 64, cross_attention_dim=96).cuda().eval()
     with torch.no_grad():
         blk.norm1.bias.normal_(), blk.norm3.bias.normal_()
-        e_n1, e_attn, e_n3, e_ff = blk._fp16_plan()
+        e_n1, e_attn, e_n3, e_ff, (q_bound, k_bound, v_bound) = blk._fp16_plan()
         x = torch.randn(4, 300, 512).cuda() * torch.logspace(-3, 3, 512).cuda()
         n1, n3 = blk.norm1(x), blk.norm3(x)
         v = blk.attn1.to_v(n1)
@@ -190,5 +190,7 @@ def test_fp16_plan_bounds_hold_and_follow_weight_updates():
         gated = hg[..., :2048] * F.gelu(hg[..., 2048:])
         for t, e in ((n1, e_n1), (v, e_attn), (n3, e_n3), (gated, e_ff)):
             assert t.abs().max().item() * 2.0 ** e <= FP16_TARGET
+        for t, bound in ((blk.attn1.to_q(n1), q_bound), (blk.attn1.to_k(n1), k_bound), (v, v_bound)):
+            assert t.abs().max().item() <= bound
         blk.norm1.weight.mul_(64.0)
         assert blk._fp16_plan()[0] == e_n1 - 6 and blk._fp16_plan()[1] <= e_attn - 5

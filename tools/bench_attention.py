@@ -24,7 +24,7 @@ for _ in range(n):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / n
 flop = 4.0 * S * S * 64 * H * B
-print(f"selfattn S={S} H={H}: {dt * 1e3:.3f} ms  {flop / dt / 1e12:.1f} TFLOP/s (fp32 MFMA peak 157)")
+print(f"selfattn S={S} H={H}: {dt * 1e3:.3f} ms  {flop / dt / 1e12:.1f} TFLOP/s fp32-equivalent (operand split + kernel + combine; fp32 MFMA peak 157)")
 
 qc, kc, vc = (t.contiguous().view(B, S, H, 64).transpose(1, 2) for t in (q, k, v))
 for _ in range(2):

@@ -77,9 +77,9 @@ def merged(patterns, path, keep=None):
 # SQ counters of the render workload's kernels (three passes) and of the transformer step (two passes), per launch
 merged(["final_pmc_sqA/*/*counter_collection.csv", "final_pmc_sqB/*/*counter_collection.csv",
         "final_pmc_sqC/*/*counter_collection.csv"], os.path.join(out, f"{tag}_bench_render_pmc_sq.csv"),
-       keep=("amav::",))
+       keep=("amav::", "_ZN4amav"))
 merged(["final_attn_pmc/*/*counter_collection.csv", "final_attn_pmc2/*/*counter_collection.csv"],
-       os.path.join(out, f"{tag}_attention_transformer_pmc_sq.csv"), keep=("amav::", "Cijk", "gemm", "Gemm"))
+       os.path.join(out, f"{tag}_attention_transformer_pmc_sq.csv"), keep=("amav::", "_ZN4amav", "Cijk", "gemm", "Gemm"))
 merged(["final_refiner_pmc/*/*counter_collection.csv"], os.path.join(out, f"{tag}_point_refiner_pmc_sq.csv"),
-       keep=("amav::", "Cijk"))
+       keep=("amav::", "_ZN4amav", "Cijk"))
 print("wrote", sorted(os.listdir(out)))

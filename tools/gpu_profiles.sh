@@ -24,7 +24,7 @@ if [ "$what" = "render" ] || [ "$what" = "all" ]; then
 fi
 if [ "$what" = "attn" ] || [ "$what" = "all" ]; then
   pass final_attn 300 --stats -- python tools/bench_attention.py
-  pass final_attn_pmc 300 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE -- python tools/bench_attention.py
+  pass final_attn_pmc 300 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE -- python tools/bench_attention.py
   pass final_attn_pmc2 300 --pmc SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_COEXEC_CYCLES SQ_WAVES -- python tools/bench_attention.py
 fi
 if [ "$what" = "refiner" ] || [ "$what" = "all" ]; then
