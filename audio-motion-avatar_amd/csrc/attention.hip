@@ -621,6 +621,30 @@ __global__ __launch_bounds__(256) void split_kv_f16_kernel(const float *__restri
     }
 }
 
+// Diagnostic build (-DAMAV_ATTN_STAMPS, tools/attention_stamps.py): per-phase shader-clock totals of every wave of
+// selfattn_f16_kernel -- stage + barrier | QK^T | max + correction + first split | PV with the pipelined splits |
+// second barrier -- summed into amav_attn_stamp_totals.  The stamps serialise the phases (the stamped kernel is ~1.6x
+// slower): read the split, not the total.
+#ifdef AMAV_ATTN_STAMPS
+__device__ unsigned long long amav_attn_stamp_totals[8];
+#define AMAV_STAMP_DECL long long stamp_prev_ = 0, stamp_acc_[6] = {0, 0, 0, 0, 0, 0};
+#define AMAV_STAMP(i_)                                                   \
+    {                                                                    \
+        const long long now_ = clock64();                                \
+        if ((i_) != 0) stamp_acc_[i_] += now_ - stamp_prev_;             \
+        stamp_prev_ = now_;                                              \
+    }
+#define AMAV_STAMP_FLUSH                                                                             \
+    if (lane == 0) {                                                                                 \
+        for (int i_ = 1; i_ < 6; ++i_) atomicAdd(&amav_attn_stamp_totals[i_], (unsigned long long)stamp_acc_[i_]); \
+        atomicAdd(&amav_attn_stamp_totals[0], 1ull);                                                 \
+    }
+#else
+#define AMAV_STAMP_DECL
+#define AMAV_STAMP(i_)
+#define AMAV_STAMP_FLUSH
+#endif
+
 __global__ __launch_bounds__(256, 3) void selfattn_f16_kernel(const float *__restrict__ q, const _Float16 *__restrict__ Kp,
                                                            const _Float16 *__restrict__ Vt, float *__restrict__ out,
                                                            int S, int Spad, long long row_stride,
@@ -687,11 +711,14 @@ __global__ __launch_bounds__(256, 3) void selfattn_f16_kernel(const float *__res
         d_[0] = make_uint2(vr_.x, vr_.y), d_[1] = make_uint2(vr_.z, vr_.w);                          \
     }
     AMAV_F16_LOAD(kt_begin)
+    AMAV_STAMP_DECL
     for (int kt = kt_begin; kt < ntiles; ++kt) {
         const int key0 = kt * kBN;
+        AMAV_STAMP(0)
         AMAV_F16_STAGE(0, 0, ka0, va0) AMAV_F16_STAGE(0, 1, ka1, va1) AMAV_F16_STAGE(1, 0, kb0, vb0)
         AMAV_F16_STAGE(1, 1, kb1, vb1)
         __syncthreads();
+        AMAV_STAMP(1)
         if (kt + 1 < ntiles) AMAV_F16_LOAD(kt + 1)
 
         // ---- raw S^T = K' Q'^T: three partial products per 16-wide k-step, small terms first
@@ -720,6 +747,7 @@ __global__ __launch_bounds__(256, 3) void selfattn_f16_kernel(const float *__res
             }
         }
         // ---- online softmax over this lane's query: the maximum of the raw scores, moved to the log2 domain once
+        AMAV_STAMP(2)
         float mx = S0[0];
 #pragma unroll
         for (int t = 1; t < 16; ++t) mx = fmaxf(mx, S0[t]);
@@ -750,6 +778,7 @@ __global__ __launch_bounds__(256, 3) void selfattn_f16_kernel(const float *__res
         };
         f16x8 Pc1, Pc2, Pn1, Pn2;
         parts(0, Pc1, Pc2);
+        AMAV_STAMP(3)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {  // u = 2 kb + s2
             const int kbase = 32 * (u >> 1) + 16 * (u & 1) + 4 * hh;
@@ -781,8 +810,11 @@ __global__ __launch_bounds__(256, 3) void selfattn_f16_kernel(const float *__res
             }
         }
         l_run = l_run * corr + psum;
+        AMAV_STAMP(4)
         __syncthreads();
+        AMAV_STAMP(5)
     }
+    AMAV_STAMP_FLUSH
 #undef AMAV_F16_LOAD
 #undef AMAV_F16_STAGE
 
@@ -1265,3 +1297,13 @@ extern "C" int amav_add_layernorm(int64_t rows, int dim, int64_t rows_per_batch,
 #undef AMAV_LN_ARGS
     return check_launch("amav_add_layernorm");
 }
+
+#ifdef AMAV_ATTN_STAMPS
+// diagnostic builds only (not declared in include/amav.h): reads and clears the phase totals
+extern "C" int amav_debug_attn_stamps(unsigned long long out[8]) {
+    unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(amav::attn::amav_attn_stamp_totals), sizeof(zero)) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(amav::attn::amav_attn_stamp_totals), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic: error of the self-attention kernels (AMAV_ATTN=f32: fp32 MFMA; default: bf16 x 3 split) against fp64 SDPA
+"""Diagnostic: error of the self-attention kernels (AMAV_ATTN=f32: fp32 MFMA; AMAV_ATTN=bf16: bf16 x 3 split; default: fp16 x 2 split) against fp64 SDPA
 at the reference shape, next to the library's fp32 SDPA."""
 import os
 import sys
