@@ -529,7 +529,7 @@ __global__ __launch_bounds__(256, 2) void selfattn_split_kernel(const float *__r
 //   S = acc 2^-(eq+ek) applied inside the exponential's fused multiply-add, no extra instruction
 //   P 2^14             the probabilities (<= 1) scaled to fp16's upper range before their split; the same factor is in
 //                      the running row sum, so it cancels in O / l, and 2^-ev is folded into the final normalisation.
-// e is chosen so the largest magnitude lands in [2^14, 2^15): no overflow, and elements down to 2^-18 of the maximum keep
+// e is chosen so the largest magnitude lands in [2^14, 2^15): no overflow, and elements down to 2^-17 of the maximum keep
 // their residual out of fp16's subnormals (below that the absolute error is under 2^-25 of the maximum).
 struct Magnitudes {  // upper bounds of |q|, |k|, |v| handed over by the caller (instead of the measured maxima)
     float q, k, v;

@@ -271,7 +271,7 @@ class BasicTransformerBlock(nn.Module):
           a projection of such a row: |W_j n (+ c_j)| <= max_j ||W_j||_2 ||n||_2 (+ max|c|)        (Cauchy-Schwarz)
           the attention output is a convex combination of value rows: |o_i| <= max|v|
           GEGLU: |h gelu(g)| <= |h| |g|.
-        The bounds overshoot typical magnitudes by 2^4..2^9; fp16 keeps a value's residual exact down to 2^-18 of the
+        The bounds overshoot typical magnitudes by 2^4..2^9; fp16 keeps a value's residual exact down to 2^-17 of the
         scaled bound, so the headroom only costs precision on elements that are already negligible."""
         ff_in = self.ff.net[0].proj
         tensors = (self.norm1.weight, self.norm1.bias, self.norm3.weight, self.norm3.bias, self.attn1.to_q.weight,

@@ -1,0 +1,124 @@
+"""CPU tests of the split-product arithmetic behind the transformer step: the number formats
+and bounds are plain mathematics, checked here in torch on the host; the kernels that implement them are checked
+against the same restatements bit for bit in tests/test_split_gemm_gpu.py."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from audio_motion_avatar_amd import transformer
+from audio_motion_avatar_amd.transformer import FP16_TARGET, BasicTransformerBlock, _memo, _scale_exp
+
+
+def split_fp16(x, e):
+    xs = x * 2.0 ** e
+    a = xs.to(torch.float16)
+    return a, (xs - a.float()).to(torch.float16)
+
+
+def split_bf16(x):
+    a = x.to(torch.bfloat16)
+    r = x - a.float()
+    b = r.to(torch.bfloat16)
+    return a, b, (r - b.float()).to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("bound", [1e-9, 0.3, 1.0, 22.6, 32768.0, 65504.0, 3e7])
+def test_scale_exp_puts_the_bound_just_under_the_target(bound):
+    e = _scale_exp(bound)
+    assert bound * 2.0 ** e <= FP16_TARGET < bound * 2.0 ** (e + 1)
+
+
+def test_scale_exp_survives_degenerate_bounds():
+    assert _scale_exp(0.0) == 100 and _scale_exp(1e300) == -100  # clamped: ldexp stays finite in fp32
+
+
+def test_fp16_parts_carry_22_bits_down_to_2_pow_minus_17_of_the_bound():
+    g = torch.Generator().manual_seed(0)
+    for bound in (37.0, 16384.0, 1.0001, 3e-4):  # scaled bound anywhere in (2^14, 2^15]
+        e = _scale_exp(bound)
+        sign = torch.randint(0, 2, (200000,), generator=g) * 2.0 - 1.0
+        x = sign * bound * 2.0 ** (-17.0 * torch.rand(200000, generator=g))
+        h1, h2 = split_fp16(x, e)
+        back = (h1.double() + h2.double()) * 2.0 ** -e
+        assert ((back - x.double()).abs() / x.double().abs()).max().item() <= 2.0 ** -21
+        assert torch.isfinite(h1).all() and h1.abs().max() <= FP16_TARGET
+        # smaller elements: the absolute error stays under 2^-38 of the bound
+        tiny = sign * bound * 2.0 ** (-17.0 - 20.0 * torch.rand(200000, generator=g))
+        t1, t2 = split_fp16(tiny, e)
+        assert ((t1.double() + t2.double()) * 2.0 ** -e - tiny.double()).abs().max().item() <= bound * 2.0 ** -38
+
+
+def test_three_fp16_partial_products_reproduce_the_fp32_product():
+    g = torch.Generator().manual_seed(1)
+    M, K, N = 64, 512, 48
+    x, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * K ** -0.5
+    ex, ew = _scale_exp(x.abs().max().item() * 16), _scale_exp(w.abs().max().item())
+    h1, h2 = split_fp16(x, ex)
+    g1, g2 = split_fp16(w, ew)
+    # the kernel's operands [h2 h1 h1] . [g1 g2 g1]^T, accumulated in fp32 like the MFMA, scaled back by alpha
+    a, b = torch.cat([h2, h1, h1], dim=1).float(), torch.cat([g1, g2, g1], dim=1).float()
+    y = (a @ b.t()) * 2.0 ** -(ex + ew)
+    ref = x.double() @ w.double().t()
+    scale = (x.double().abs() @ w.double().abs().t())  # sum of |x||w|: what the rounding errors are relative to
+    assert ((y.double() - ref).abs() / scale).max().item() <= 2.0 ** -20
+    assert (y.double() - ref).abs().max() <= 5e-6  # outputs are O(1): fp32 accumulation over K = 512, as in any fp32 GEMM
+
+
+def test_six_bf16_partial_products_reproduce_the_fp32_product():
+    g = torch.Generator().manual_seed(2)
+    x, w = torch.randn(32, 256, generator=g) * 1e3, torch.randn(24, 256, generator=g) * 1e-4  # no scaling needed
+    x1, x2, x3 = split_bf16(x)
+    w1, w2, w3 = split_bf16(w)
+    a = torch.cat([x3, x2, x1, x2, x1, x1], dim=1).float()
+    b = torch.cat([w1, w2, w3, w1, w2, w1], dim=1).float()
+    ref = x.double() @ w.double().t()
+    scale = x.double().abs() @ w.double().abs().t()
+    assert (((a @ b.t()).double() - ref).abs() / scale).max().item() <= 2.0 ** -21
+
+
+def test_fp16_plan_bounds_hold_for_adversarial_rows():
+    torch.manual_seed(3)
+    blk = BasicTransformerBlock(256, 4, 64, cross_attention_dim=32).eval()
+    with torch.no_grad():
+        blk.norm1.weight.uniform_(-3, 3), blk.norm1.bias.normal_(0, 2)
+        blk.norm3.weight.uniform_(-3, 3), blk.norm3.bias.normal_(0, 2)
+        e_n1, e_attn, e_n3, e_ff, (qb, kb, vb) = blk._fp16_plan()
+        spikes = torch.zeros(256, 256)
+        spikes[torch.arange(256), torch.arange(256)] = 1e6          # one channel carries the row: |z| = sqrt(dim - 1)
+        x = torch.cat([spikes, -spikes, torch.randn(64, 256), torch.randn(64, 256) * 1e-6]).unsqueeze(0)
+        n1, n3 = blk.norm1(x), blk.norm3(x)
+        q, k, v = blk.attn1.to_q(n1), blk.attn1.to_k(n1), blk.attn1.to_v(n1)
+        hg = blk.ff.net[0].proj(n3)
+        gated = hg[..., :1024] * F.gelu(hg[..., 1024:])
+        for t, e in ((n1, e_n1), (v, e_attn), (n3, e_n3), (gated, e_ff)):
+            assert t.abs().max().item() * 2.0 ** e <= FP16_TARGET
+        for t, bound in ((q, qb), (k, kb), (v, vb)):
+            assert t.abs().max().item() <= bound
+        # the bounds are not vacuous: within 2^10 of what such rows reach
+        assert n1.abs().max().item() * 2.0 ** e_n1 >= FP16_TARGET / 4 and v.abs().max().item() >= vb / 1024
+
+
+def test_memo_follows_in_place_updates_reallocation_and_release():
+    w = torch.nn.Parameter(torch.ones(4))
+    calls = []
+    make = lambda: calls.append(1) or float(w.detach().sum())
+    assert _memo("t", (w,), make) == 4.0 and _memo("t", (w,), make) == 4.0 and len(calls) == 1
+    with torch.no_grad():
+        w.mul_(2.0)
+    assert _memo("t", (w,), make) == 8.0 and len(calls) == 2
+    w.data = torch.full((4,), 3.0)  # e.g. load_state_dict(assign=True) / .to(device)
+    assert _memo("t", (w,), make) == 12.0 and len(calls) == 3
+    key = ("t", id(w))
+    assert key in transformer._MEMO
+    del w, make
+    import gc
+    gc.collect()
+    assert key not in transformer._MEMO
+
+
+def test_linear_takes_the_library_path_on_cpu_and_under_autograd():
+    x, lin = torch.randn(300, 64), torch.nn.Linear(64, 32)
+    assert torch.equal(transformer.linear(x, lin.weight, lin.bias), F.linear(x, lin.weight, lin.bias))
+    assert transformer.linear(x, lin.weight, lin.bias).requires_grad
