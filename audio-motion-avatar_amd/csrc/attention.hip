@@ -568,7 +568,9 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ q
     }
 }
 
-// grid (key tiles of 64, H, B), 256 threads: as split_kv_kernel, two fp16 parts of K 2^ek and V 2^ev
+// grid (key tiles of 64, H, B), 256 threads: as split_kv_kernel, two fp16 parts of K 2^ek and V 2^ev.  V^T rows store
+// every group of 16 keys in the order the accumulator-as-operand product reads them: positions 0-7 = keys 0-3, 8-11
+// (lane half 0), positions 8-15 = keys 4-7, 12-15 (lane half 1).
 __global__ __launch_bounds__(256) void split_kv_f16_kernel(const float *__restrict__ k, const float *__restrict__ v, int S,
                                                            int Spad, long long row_stride,
                                                            const unsigned *__restrict__ hdr, Magnitudes given,
@@ -582,42 +584,49 @@ __global__ __launch_bounds__(256) void split_kv_f16_kernel(const float *__restri
     const int key = tid >> 2, d0 = (tid & 3) * 16;
     const bool live = key0 + key < S;
     const size_t src = ((size_t)b * S + min(key0 + key, S - 1)) * row_stride + head * kD + d0;
+    float kk[16];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const float4 kv = *reinterpret_cast<const float4 *>(k + src + 4 * q);
         const float4 vv = *reinterpret_cast<const float4 *>(v + src + 4 * q);
-        const float kk[4] = {kv.x, kv.y, kv.z, kv.w};
-        f16x4 p1, p2;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            _Float16 a, bb;
-            split2(kk[e] * sk, a, bb);
-            p1[e] = a, p2[e] = bb;
-        }
-        if (live) {
-            _Float16 *dst = Kp + (bh * S + key0 + key) * kD + d0 + 4 * q;
-            *reinterpret_cast<f16x4 *>(dst) = p1;
-            *reinterpret_cast<f16x4 *>(dst + part_k) = p2;
-        }
+        kk[4 * q] = kv.x, kk[4 * q + 1] = kv.y, kk[4 * q + 2] = kv.z, kk[4 * q + 3] = kv.w;
         vt[d0 + 4 * q + 0][key] = live ? vv.x * sv : 0.f;
         vt[d0 + 4 * q + 1][key] = live ? vv.y * sv : 0.f;
         vt[d0 + 4 * q + 2][key] = live ? vv.z * sv : 0.f;
         vt[d0 + 4 * q + 3][key] = live ? vv.w * sv : 0.f;
     }
+    if (live) {  // 16 consecutive d of one key: two 16-byte stores per part
+        _Float16 *dst = Kp + (bh * S + key0 + key) * kD + d0;
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            f16x8 p1, p2;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                _Float16 a, bb;
+                split2(kk[8 * o + e] * sk, a, bb);
+                p1[e] = a, p2[e] = bb;
+            }
+            *reinterpret_cast<f16x8 *>(dst + 8 * o) = p1;
+            *reinterpret_cast<f16x8 *>(dst + part_k + 8 * o) = p2;
+        }
+    }
     __syncthreads();
+    // thread -> d tid / 4, the 16-key group (tid % 4); inside a group the keys are stored in the order the PV product's
+    // A operand wants them: lane half hh of selfattn_f16_kernel then reads its 8 keys as one 16-byte piece
     const int d = tid >> 2, kq = (tid & 3) * 16;
+    _Float16 *dst = Vt + (bh * kD + d) * Spad + key0 + kq;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        f16x4 p1, p2;
+    for (int o = 0; o < 2; ++o) {
+        f16x8 p1, p2;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < 8; ++e) {
+            const int pos = 8 * o + e;  // position in the group -> key 8 ((pos & 7) >> 2) + 4 (pos >> 3) + (pos & 3)
             _Float16 a, bb;
-            split2(vt[d][kq + 4 * q + e], a, bb);
+            split2(vt[d][kq + 8 * ((pos & 7) >> 2) + 4 * (pos >> 3) + (pos & 3)], a, bb);
             p1[e] = a, p2[e] = bb;
         }
-        _Float16 *dst = Vt + (bh * kD + d) * Spad + key0 + kq + 4 * q;
-        *reinterpret_cast<f16x4 *>(dst) = p1;
-        *reinterpret_cast<f16x4 *>(dst + part_v) = p2;
+        *reinterpret_cast<f16x8 *>(dst + 8 * o) = p1;
+        *reinterpret_cast<f16x8 *>(dst + part_v + 8 * o) = p2;
     }
 }
 
@@ -652,7 +661,7 @@ __global__ __launch_bounds__(256, 3) void selfattn_f16_kernel(const float *__res
                                                            float *__restrict__ part, const unsigned *__restrict__ hdr,
                                                            Magnitudes given, int H, int B, int q_tiles) {
     __shared__ _Float16 Ks[2][kBN * kLdK];  // [part][key][d]
-    __shared__ _Float16 Vs[2][kD * kLdV];   // [part][d][key]
+    __shared__ _Float16 Vs[2][kD * kLdK];   // [part][d][key, in the group order of split_kv_f16_kernel]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r = lane & 31, hh = lane >> 5;
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
@@ -707,8 +716,7 @@ __global__ __launch_bounds__(256, 3) void selfattn_f16_kernel(const float *__res
 #define AMAV_F16_STAGE(p_, i_, kr_, vr_)                                                             \
     {                                                                                                \
         *reinterpret_cast<uint4 *>(&Ks[p_][(srow0 + 32 * (i_)) * kLdK + sc8]) = kr_;                 \
-        uint2 *d_ = reinterpret_cast<uint2 *>(&Vs[p_][(srow0 + 32 * (i_)) * kLdV + sc8]); /* 136-byte rows: 8-byte aligned */ \
-        d_[0] = make_uint2(vr_.x, vr_.y), d_[1] = make_uint2(vr_.z, vr_.w);                          \
+        *reinterpret_cast<uint4 *>(&Vs[p_][(srow0 + 32 * (i_)) * kLdK + sc8]) = vr_;                 \
     }
     AMAV_F16_LOAD(kt_begin)
     AMAV_STAMP_DECL
@@ -781,18 +789,12 @@ __global__ __launch_bounds__(256, 3) void selfattn_f16_kernel(const float *__res
         AMAV_STAMP(3)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {  // u = 2 kb + s2
-            const int kbase = 32 * (u >> 1) + 16 * (u & 1) + 4 * hh;
-            f16x8 vf[2][2];
+            f16x8 vf[2][2];  // this lane half's 8 keys of k-step u: one 16-byte piece (group order)
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    const _Float16 *src = &Vs[p][(r + 32 * a) * kLdV + kbase];
-                    const f16x4 lo = *reinterpret_cast<const f16x4 *>(src);
-                    const f16x4 hi = *reinterpret_cast<const f16x4 *>(src + 8);
-                    vf[a][p][0] = lo[0], vf[a][p][1] = lo[1], vf[a][p][2] = lo[2], vf[a][p][3] = lo[3];
-                    vf[a][p][4] = hi[0], vf[a][p][5] = hi[1], vf[a][p][6] = hi[2], vf[a][p][7] = hi[3];
-                }
+                for (int p = 0; p < 2; ++p)
+                    vf[a][p] = *reinterpret_cast<const f16x8 *>(&Vs[p][(r + 32 * a) * kLdK + 16 * u + 8 * hh]);
             if (u + 1 < 4) parts(u + 1, Pn1, Pn2);
             O0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[0][1], Pc1, O0, 0, 0, 0);
             O1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[1][1], Pc1, O1, 0, 0, 0);
