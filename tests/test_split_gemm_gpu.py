@@ -194,3 +194,20 @@ def test_fp16_plan_bounds_hold_and_follow_weight_updates():
             assert t.abs().max().item() <= bound
         blk.norm1.weight.mul_(64.0)
         assert blk._fp16_plan()[0] == e_n1 - 6 and blk._fp16_plan()[1] <= e_attn - 5
+
+
+@pytest.mark.parametrize("B,S,heads", [(2, 301, 4), (3, 130, 12), (1, 257, 16)])
+def test_fused_block_other_widths_and_batches(monkeypatch, B, S, heads):
+    """dim = 64 * heads in {256, 768, 1024}: the other LayerNorm widths of add_layernorm_kernel's split output, batch > 1
+    (one cross-attention row per batch item), sequence lengths that are not tile multiples."""
+    from audio_motion_avatar_amd.transformer import Transformer1D_nn
+
+    torch.manual_seed(B * S)
+    net = Transformer1D_nn(heads, 64, in_channels=32, num_layers=2, cross_attention_dim=48).cuda().eval()
+    x, ctx = torch.randn(B, 32, S).cuda(), torch.randn(B, 1, 48).cuda()
+    with torch.no_grad():
+        y = net(x, ctx)
+        monkeypatch.setenv("AMAV_GEMM", "f32")
+        y32 = net(x, ctx)
+    assert torch.isfinite(y).all()
+    assert (y - y32).abs().max() <= 2e-5 * max(1.0, y32.abs().max().item())
