@@ -98,7 +98,7 @@ def fp16_gemm_ok(rows, K):
 
 
 def linear_presplit(a, weight, bias=None):
-    """a: the [rows, 6 K] bf16 activation operand (ops.split_operand / ops.add_layernorm(split=True)) -> [rows, N] fp32
+    """a: the [rows, 6 K] bf16 activation operand (ops.split_operand / ops.add_layernorm(split=SPLIT_BF16X3)) -> [rows, N] fp32
     = x weight^T (+ bias).  A bias costs a pass over the output here (the library adds it as a pre-filled C): callers on
     the hot path hand it to the kernel that consumes the result instead (ops.geglu / ops.add_layernorm)."""
     b = _split_weight(weight)
