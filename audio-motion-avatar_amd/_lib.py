@@ -46,7 +46,7 @@ class BodyTables(ctypes.Structure):
         ("skin_k", ctypes.c_int32),
         ("v_template", ctypes.c_void_p), ("blend", ctypes.c_void_p), ("j_template", ctypes.c_void_p),
         ("j_dirs", ctypes.c_void_p), ("parents", ctypes.c_void_p), ("skin_idx", ctypes.c_void_p),
-        ("skin_w", ctypes.c_void_p),
+        ("skin_w", ctypes.c_void_p), ("blend_split", ctypes.c_void_p),
     ]
 
 
@@ -122,6 +122,9 @@ SIGNATURES = {
     "amav_unpool_merge": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, c_float_p, c_float_p, c_float_p, c_float_p,
                                          ctypes.c_void_p, c_float_p, c_float_p, ctypes.c_void_p]),
     "amav_lbs_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.POINTER(BodyTables)]),
+    "amav_lbs_blend_split_bytes": (ctypes.c_size_t, [ctypes.POINTER(BodyTables)]),
+    "amav_lbs_prepare_blend_split": (ctypes.c_int, [ctypes.POINTER(BodyTables), ctypes.c_void_p, ctypes.c_size_t,
+                                                    ctypes.c_void_p]),
     "amav_lbs_forward": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(BodyTables), c_float_p, c_float_p, c_float_p,
                                         c_float_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "amav_points_gather": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_float_p, ctypes.c_void_p,

@@ -313,8 +313,18 @@ class BodyModel(torch.nn.Module):
 
     # ---- tables for the C ABI ----------------------------------------------------------------------------------
     def device_tables(self) -> dict:
-        return dict(v_template=self.v_template, blend=self._blend, j_template=self._j_template, j_dirs=self._j_dirs,
-                    parents=self._parents32, skin_idx=self._skin_idx, skin_w=self._skin_w)
+        tables = dict(v_template=self.v_template, blend=self._blend, j_template=self._j_template, j_dirs=self._j_dirs,
+                      parents=self._parents32, skin_idx=self._skin_idx, skin_w=self._skin_w)
+        if self._blend.is_cuda:
+            # the blend table as two fp16 parts for the 16-bit matrix pipe (csrc/lbs.hip, skin_f16_kernel), built once
+            # per device placement of the table
+            key = (self._blend.data_ptr(), self._blend._version)
+            if getattr(self, "_blend_split", None) is None or self._blend_split[0] != key:
+                from . import ops
+
+                self._blend_split = (key, ops.lbs_prepare_blend_split(tables))
+            tables["blend_split"] = self._blend_split[1]
+        return tables
 
     def oracle_arrays(self, dtype=torch.float32) -> dict:
         """The model as plain CPU tensors (what tests hand to oracle.lbs; no product code consumes this)."""

@@ -14,8 +14,16 @@
 //   skin_kernel         (F <= 16) one thread per vertex and FT frames: the same product as register-tiled FMAs with
 //                       the group's feature slice in LDS; the frame groups of a vertex chunk share an XCD, so a
 //                       chunk of the 63.6 MB table is fetched from HBM once.  Nothing but the vertices is written.
+//   skin_f16_kernel     the MFMA kernel on the 16-bit matrix pipe: features and table as two fp16 parts each, three
+//                       partial products per fp32 product on v_mfma_f32_32x32x16_f16 (16x the fp32 MFMA rate), fp32
+//                       accumulation -- the fp32 product to 2^-22.  Needs the table pre-split
+//                       (amav_lbs_prepare_blend_split); every frame's features are pre-scaled by their own power of
+//                       two, taken back out in the epilogue.
 //   gather_kernel       baked subdivision table -> the N sampled points.
+#include <algorithm>
+#include <cmath>
 #include <cstdlib>
+#include <cstring>
 
 #include "amav_common.h"
 
@@ -29,6 +37,7 @@ struct Tables {
     const float *v_template, *blend, *j_template, *j_dirs;
     const int *parents, *skin_idx;
     const float *skin_w;
+    const void *blend_split;  // fp16 x 2 form of `blend` (amav_lbs_prepare_blend_split) or NULL
 };
 
 __global__ __launch_bounds__(64) void joint_chain_kernel(Tables t, int F, int Fpad, const float *__restrict__ full_pose,
@@ -343,6 +352,236 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 3) void skin_mfma_kernel(Tables t,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// fp16 x 2 form of the blend product (the split-product arithmetic of csrc/attention.hip):
+//   x 2^e = h1 + h2 (two fp16 parts, 22 bits),   a b = (a1 b1 + a1 b2 + a2 b1) 2^-(ea + eb)   to 2^-22,
+// three v_mfma_f32_32x32x16_f16 per fp32 product, each 8 x the k depth of the fp32 MFMA at half its cycles.
+// Scaling (exact powers of two): the table by ONE exponent from its largest magnitude (static, prepared once); every
+// frame's feature column by its own exponent from that frame's largest feature (split_features_kernel), undone per
+// accumulator row in the epilogue.  Both put the largest magnitude in [2^14, 2^15): nothing overflows, and entries
+// down to 2^-17 of the largest keep all 22 bits (smaller ones an absolute error below 2^-39 of it).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr size_t kSplitHeaderBytes = 256;  // [0]: float, largest |table entry|; [1]: int, the table's scale exponent
+
+__device__ __forceinline__ int f16_scale_exp(float amax) {
+    if (!(amax > 0.f)) return 0;
+    return max(-100, min(100, 14 - ilogbf(amax)));
+}
+__device__ __forceinline__ void split2(float x, _Float16 &a, _Float16 &b) {
+    a = (_Float16)x;
+    b = (_Float16)__builtin_fmaf((float)a, -1.0f, x);
+}
+static inline int k16_of(int KB) { return (KB + 31) / 32 * 32; }  // table rows padded to whole 32-row chunks
+
+__global__ __launch_bounds__(256) void table_absmax_kernel(const float4 *__restrict__ blend4, long long n4,
+                                                           unsigned *__restrict__ hdr) {
+    float m = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const float4 v = blend4[i];
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    __shared__ float wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(hdr, __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
+}
+
+// blend [tile][KB][3][32] fp32 -> split [tile][k-step of 16][part][comp][lane half hh][vertex c][8 k] fp16: the B operand
+// fragment of lane (c, hh) for one (k-step, part, component) is 16 contiguous bytes, and a 32-row chunk is 12 KB that
+// the skin kernel copies to LDS as is.  One thread per (tile, k-step, comp, hh, c): 8 strided reads, two 16-byte writes.
+__global__ __launch_bounds__(256) void table_split_kernel(const float *__restrict__ blend, int KB, int K16, long long items,
+                                                          unsigned *__restrict__ hdr, _Float16 *__restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = f16_scale_exp(__uint_as_float(hdr[0]));
+    if (i == 0) reinterpret_cast<int *>(hdr)[1] = e;
+    if (i >= items) return;
+    const int c = (int)(i & 31), hh = (int)((i >> 5) & 1), comp = (int)((i >> 6) % 3);
+    const long long rest = (i >> 6) / 3;  // tile * steps + step
+    const int steps = K16 / 16, step = (int)(rest % steps);
+    const long long tile = rest / steps;
+    const float scale = ldexpf(1.0f, e);
+    f16x8 p1, p2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 16 * step + 8 * hh + j;
+        const float x = k < KB ? blend[((tile * KB + k) * 3 + comp) * 32 + c] : 0.f;
+        _Float16 a, b;
+        split2(x * scale, a, b);
+        p1[j] = a, p2[j] = b;
+    }
+    _Float16 *dst = out + (((tile * steps + step) * 2) * 3 + comp) * 512 + hh * 256 + c * 8;
+    *reinterpret_cast<f16x8 *>(dst) = p1;
+    *reinterpret_cast<f16x8 *>(dst + 3 * 512) = p2;
+}
+
+// one 64-lane block per frame: the frame's largest |feature| -> its scale exponent; featT [k][Fpad] fp32 ->
+// featH [part][k / 8][Fpad][8] fp16 (lane (frame, hh) of the skin kernel reads 16 contiguous bytes per part and k-step)
+// and fscale[frame] = 2^-(e_frame + e_table) for the epilogue.  Rows KB..K16-1 are zero.
+__global__ __launch_bounds__(64) void split_features_kernel(int KB, int K16, int F, int Fpad, const float *__restrict__ featT,
+                                                           const unsigned *__restrict__ hdr, _Float16 *__restrict__ featH,
+                                                           float *__restrict__ fscale) {
+    const int f = blockIdx.x, lane = threadIdx.x;
+    const bool live = f < F;  // padded frames: zero features, scale 1
+    float m = 0.f;
+    for (int k = lane; k < KB; k += 64) m = fmaxf(m, live ? fabsf(featT[(size_t)k * Fpad + f]) : 0.f);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    const int e = f16_scale_exp(m);
+    const float scale = ldexpf(1.0f, e);
+    if (lane == 0) fscale[f] = ldexpf(1.0f, -(e + reinterpret_cast<const int *>(hdr)[1]));
+    const size_t part = (size_t)(K16 / 8) * Fpad * 8;
+    for (int k8 = lane; k8 < K16 / 8; k8 += 64) {
+        f16x8 p1, p2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 8 * k8 + j;
+            const float x = (live && k < KB) ? featT[(size_t)k * Fpad + f] : 0.f;
+            _Float16 a, b;
+            split2(x * scale, a, b);
+            p1[j] = a, p2[j] = b;
+        }
+        _Float16 *dst = featH + ((size_t)k8 * Fpad + f) * 8;
+        *reinterpret_cast<f16x8 *>(dst) = p1;
+        *reinterpret_cast<f16x8 *>(dst + part) = p2;
+    }
+}
+
+// Same decomposition as skin_mfma_kernel (block = 4 waves = 128 frames x one 32-vertex tile, the tile's table slab
+// streamed once through double-buffered LDS in 12 KB chunks of 32 rows, one barrier per chunk); per chunk a wave issues
+// 2 k-steps x 3 components x 3 partial products = 18 MFMAs of 32 cycles where the fp32 kernel issues 48 of 64.
+__global__ __launch_bounds__(64 * kMfmaWaves, 3) void skin_f16_kernel(Tables t, int F, int Fpad, int ntiles, int K16,
+                                                                   const _Float16 *__restrict__ featH,
+                                                                   const float *__restrict__ fscale,
+                                                                   const float *__restrict__ A,
+                                                                   float *__restrict__ out) {
+    __shared__ float4 Bs[2][kMfmaChunk4];
+    const int ngroups = (Fpad / 32 + kMfmaWaves - 1) / kMfmaWaves;
+    const int xcd = blockIdx.x & 7, bj = blockIdx.x >> 3;
+    const int tile = (bj / ngroups) * 8 + xcd, fg = bj % ngroups;
+    if (tile >= ntiles) return;  // block-uniform
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ftile = fg * kMfmaWaves + wave;
+    const bool active = ftile * 32 < Fpad;
+    const int f0 = active ? ftile * 32 : 0;
+    const int c = lane & 31, hh = lane >> 5;
+    const int v = tile * 32 + c;
+
+    f32x16 X, Y, Z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) X[r] = 0.f, Y[r] = 0.f, Z[r] = 0.f;
+    const int nchunks = K16 / kMfmaKC;
+    const float4 *bt4 = reinterpret_cast<const float4 *>(static_cast<const char *>(t.blend_split) + kSplitHeaderBytes) +
+                        (size_t)tile * nchunks * kMfmaChunk4;
+    // A fragments: lane (frame f0 + c, hh), k-step s of chunk ch: featH[part][(ch * 32 + 16 s) / 8 + hh][frame][0..7]
+    const size_t part_a = (size_t)(K16 / 8) * Fpad * 8;
+    const _Float16 *fa = featH + ((size_t)hh * Fpad + f0 + c) * 8;
+    // named registers and macros: arrays captured by lambdas were demoted to scratch memory here
+    float4 breg0, breg1, breg2;
+    f16x8 ac00, ac01, ac10, ac11, an00, an01, an10, an11;  // a{c: current, n: next}{k-step}{part}
+#define AMAV_LBS_GLOAD(ch_)                                              \
+    {                                                                    \
+        const float4 *src_ = bt4 + (size_t)(ch_) * kMfmaChunk4 + threadIdx.x; \
+        breg0 = src_[0], breg1 = src_[256], breg2 = src_[512];           \
+    }
+#define AMAV_LBS_ALOAD(a00_, a01_, a10_, a11_, ch_)                                          \
+    {                                                                                        \
+        const _Float16 *p_ = fa + (size_t)((ch_) * 4) * Fpad * 8;                            \
+        a00_ = *reinterpret_cast<const f16x8 *>(p_);                                         \
+        a01_ = *reinterpret_cast<const f16x8 *>(p_ + part_a);                                \
+        a10_ = *reinterpret_cast<const f16x8 *>(p_ + (size_t)2 * Fpad * 8);                  \
+        a11_ = *reinterpret_cast<const f16x8 *>(p_ + (size_t)2 * Fpad * 8 + part_a);         \
+    }
+#define AMAV_LBS_STAGE(buf_) \
+    Bs[buf_][threadIdx.x] = breg0, Bs[buf_][threadIdx.x + 256] = breg1, Bs[buf_][threadIdx.x + 512] = breg2;
+#define AMAV_LBS_STEP(s_, a1_, a2_)                                                                        \
+    {                                                                                                      \
+        /* fragment (k-step s, part p, component q) at ((s * 2 + p) * 3 + q) * 512 halfs */                \
+        const f16x8 x1 = *reinterpret_cast<const f16x8 *>(bs + (((s_) * 2 + 0) * 3 + 0) * 512);            \
+        const f16x8 y1 = *reinterpret_cast<const f16x8 *>(bs + (((s_) * 2 + 0) * 3 + 1) * 512);            \
+        const f16x8 z1 = *reinterpret_cast<const f16x8 *>(bs + (((s_) * 2 + 0) * 3 + 2) * 512);            \
+        const f16x8 x2 = *reinterpret_cast<const f16x8 *>(bs + (((s_) * 2 + 1) * 3 + 0) * 512);            \
+        const f16x8 y2 = *reinterpret_cast<const f16x8 *>(bs + (((s_) * 2 + 1) * 3 + 1) * 512);            \
+        const f16x8 z2 = *reinterpret_cast<const f16x8 *>(bs + (((s_) * 2 + 1) * 3 + 2) * 512);            \
+        X = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2_, x1, X, 0, 0, 0); /* small terms first */           \
+        Y = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2_, y1, Y, 0, 0, 0);                                   \
+        Z = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2_, z1, Z, 0, 0, 0);                                   \
+        X = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1_, x2, X, 0, 0, 0);                                   \
+        Y = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1_, y2, Y, 0, 0, 0);                                   \
+        Z = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1_, z2, Z, 0, 0, 0);                                   \
+        X = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1_, x1, X, 0, 0, 0);                                   \
+        Y = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1_, y1, Y, 0, 0, 0);                                   \
+        Z = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1_, z1, Z, 0, 0, 0);                                   \
+    }
+    AMAV_LBS_GLOAD(0)
+    AMAV_LBS_ALOAD(ac00, ac01, ac10, ac11, 0)
+    AMAV_LBS_STAGE(0)
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int buf = ch & 1;
+        const int nxt = min(ch + 1, nchunks - 1);  // always issued, as in skin_mfma_kernel
+        AMAV_LBS_GLOAD(nxt)
+        AMAV_LBS_ALOAD(an00, an01, an10, an11, nxt)
+        __builtin_amdgcn_sched_barrier(0);
+        if (active) {
+            const _Float16 *bs = reinterpret_cast<const _Float16 *>(Bs[buf]) + hh * 256 + c * 8;
+            AMAV_LBS_STEP(0, ac00, ac01)
+            AMAV_LBS_STEP(1, ac10, ac11)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        AMAV_LBS_STAGE(buf ^ 1)
+        ac00 = an00, ac01 = an01, ac10 = an10, ac11 = an11;
+        __syncthreads();
+    }
+#undef AMAV_LBS_GLOAD
+#undef AMAV_LBS_ALOAD
+#undef AMAV_LBS_STAGE
+#undef AMAV_LBS_STEP
+    if (!active) return;
+    if (v >= t.V) return;
+
+    const float tx = t.v_template[v * 3], ty = t.v_template[v * 3 + 1], tz = t.v_template[v * 3 + 2];
+    float fs_all[16];  // the scale of every accumulator row's frame
+#pragma unroll
+    for (int r = 0; r < 16; ++r) fs_all[r] = fscale[min(f0 + 8 * (r >> 2) + 4 * hh + (r & 3), Fpad - 1)];
+    int jidx[8];
+    float jw[8];
+    const int kw = t.KW;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        jidx[k] = k < kw ? t.skin_idx[(size_t)v * kw + k] : 0;
+        jw[k] = k < kw ? t.skin_w[(size_t)v * kw + k] : 0.0f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int f = f0 + 8 * (r >> 2) + 4 * hh + (r & 3);
+        if (f >= F) continue;
+        float Tm[12];
+#pragma unroll
+        for (int e = 0; e < 12; ++e) Tm[e] = 0.0f;
+        const float *Af = A + (size_t)f * t.J * 12;
+        auto add = [&](int ji, float w) {
+            const float4 *a4 = reinterpret_cast<const float4 *>(Af + ji * 12);
+            const float4 r0 = a4[0], r1 = a4[1], r2 = a4[2];
+            Tm[0] += w * r0.x, Tm[1] += w * r0.y, Tm[2] += w * r0.z, Tm[3] += w * r0.w;
+            Tm[4] += w * r1.x, Tm[5] += w * r1.y, Tm[6] += w * r1.z, Tm[7] += w * r1.w;
+            Tm[8] += w * r2.x, Tm[9] += w * r2.y, Tm[10] += w * r2.z, Tm[11] += w * r2.w;
+        };
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (k < kw) add(jidx[k], jw[k]);
+        for (int k = 8; k < kw; ++k) add(t.skin_idx[(size_t)v * kw + k], t.skin_w[(size_t)v * kw + k]);
+        const float fs = fs_all[r];
+        const float x = tx + X[r] * fs, y = ty + Y[r] * fs, z = tz + Z[r] * fs;
+        float *o = out + ((size_t)f * t.V + v) * 3;
+        o[0] = Tm[0] * x + Tm[1] * y + Tm[2] * z + Tm[3];
+        o[1] = Tm[4] * x + Tm[5] * y + Tm[6] * z + Tm[7];
+        o[2] = Tm[8] * x + Tm[9] * y + Tm[10] * z + Tm[11];
+    }
+}
+
 __global__ __launch_bounds__(256) void gather_kernel(int V, int N, const float *__restrict__ verts,
                                                      const int4 *__restrict__ idx, float *__restrict__ out) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -386,7 +625,17 @@ static int validate_tables(const amav_body_tables *t, const char *who) {
     return AMAV_OK;
 }
 
-static size_t lbs_ws(int F, const amav_body_tables *t, float **featT, float **A, void *ws) {
+// AMAV_LBS=f32 keeps the fp32 MFMA kernel even when the tables carry a split blend table
+static bool lbs_use_split(const amav_body_tables *t, int FT) {
+    static const bool off = [] {
+        const char *e = getenv("AMAV_LBS");
+        return e && strcmp(e, "f32") == 0;
+    }();
+    return FT == 0 && t->blend_split != nullptr && !off;
+}
+
+static size_t lbs_ws(int F, const amav_body_tables *t, float **featT, float **A, void *ws, _Float16 **featH = nullptr,
+                     float **fscale = nullptr) {
     const int KB = t->num_coeffs + (t->num_joints - 1) * 9;
     const int FT = frame_tile(F, KB);
     const int Fpad = frame_pad(F, FT);
@@ -395,7 +644,44 @@ static size_t lbs_ws(int F, const amav_body_tables *t, float **featT, float **A,
     float *a = c.take<float>((size_t)Fpad * t->num_joints * 12);
     if (featT) *featT = ft;
     if (A) *A = a;
+    if (lbs_use_split(t, FT)) {
+        _Float16 *fh = c.take<_Float16>((size_t)2 * k16_of(KB) * Fpad);
+        float *fs = c.take<float>((size_t)Fpad);
+        if (featH) *featH = fh;
+        if (fscale) *fscale = fs;
+    }
     return c.total();
+}
+
+static size_t blend_split_bytes(const amav_body_tables *t) {
+    const int KB = t->num_coeffs + (t->num_joints - 1) * 9;
+    const size_t ntiles = ((size_t)t->num_verts + 31) / 32;
+    return kSplitHeaderBytes + ntiles * (k16_of(KB) / 16) * 2 * 3 * 512 * sizeof(_Float16);
+}
+
+extern "C" size_t amav_lbs_blend_split_bytes(const amav_body_tables *t) {
+    if (validate_tables(t, "amav_lbs_blend_split_bytes") != AMAV_OK) return 0;
+    return blend_split_bytes(t);
+}
+
+extern "C" int amav_lbs_prepare_blend_split(const amav_body_tables *tb, void *out, size_t out_bytes, void *stream_) {
+    if (int rc = validate_tables(tb, "amav_lbs_prepare_blend_split")) return rc;
+    AMAV_REQUIRE(out && (reinterpret_cast<uintptr_t>(out) & 255) == 0, "amav_lbs_prepare_blend_split: out must be 256-byte aligned");
+    const size_t need = blend_split_bytes(tb);
+    if (out_bytes < need)
+        return fail(AMAV_ERR_WORKSPACE, "amav_lbs_prepare_blend_split: buffer %zu < required %zu", out_bytes, need);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int KB = tb->num_coeffs + (tb->num_joints - 1) * 9, K16 = k16_of(KB);
+    const long long ntiles = (tb->num_verts + 31) / 32;
+    unsigned *hdr = static_cast<unsigned *>(out);
+    AMAV_REQUIRE(hipMemsetAsync(hdr, 0, kSplitHeaderBytes, stream) == hipSuccess, "amav_lbs_prepare_blend_split: memset failed");
+    const long long n4 = ntiles * KB * 24;
+    table_absmax_kernel<<<(unsigned)std::min<long long>((n4 + 255) / 256, 512), 256, 0, stream>>>(
+        reinterpret_cast<const float4 *>(tb->blend), n4, hdr);
+    const long long items = ntiles * (K16 / 16) * 3 * 64;
+    table_split_kernel<<<(unsigned)((items + 255) / 256), 256, 0, stream>>>(
+        tb->blend, KB, K16, items, hdr, reinterpret_cast<_Float16 *>(static_cast<char *>(out) + kSplitHeaderBytes));
+    return check_launch("amav_lbs_prepare_blend_split");
 }
 
 extern "C" size_t amav_lbs_workspace_bytes(int F, const amav_body_tables *t) {
@@ -409,15 +695,16 @@ extern "C" int amav_lbs_forward(int F, const amav_body_tables *tb, const float *
     AMAV_REQUIRE(F > 0, "amav_lbs_forward: F=%d", F);
     if (int rc = validate_tables(tb, "amav_lbs_forward")) return rc;
     AMAV_REQUIRE(full_pose && coeffs && out_vertices && workspace, "amav_lbs_forward: NULL pointer");
-    float *featT = nullptr, *A = nullptr;
-    const size_t need = lbs_ws(F, tb, &featT, &A, workspace);
+    float *featT = nullptr, *A = nullptr, *fscale = nullptr;
+    _Float16 *featH = nullptr;
+    const size_t need = lbs_ws(F, tb, &featT, &A, workspace, &featH, &fscale);
     if (workspace_bytes < need)
         return fail(AMAV_ERR_WORKSPACE, "amav_lbs_forward: workspace %zu < required %zu", workspace_bytes, need);
     Tables t;
     t.V = tb->num_verts, t.J = tb->num_joints, t.NC = tb->num_coeffs, t.KW = tb->skin_k;
     t.KB = t.NC + (t.J - 1) * 9;
     t.v_template = tb->v_template, t.blend = tb->blend, t.j_template = tb->j_template, t.j_dirs = tb->j_dirs;
-    t.parents = tb->parents, t.skin_idx = tb->skin_idx, t.skin_w = tb->skin_w;
+    t.parents = tb->parents, t.skin_idx = tb->skin_idx, t.skin_w = tb->skin_w, t.blend_split = tb->blend_split;
     const int FT = frame_tile(F, t.KB);
     const int Fpad = frame_pad(F, FT);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -431,7 +718,15 @@ extern "C" int amav_lbs_forward(int F, const amav_body_tables *tb, const float *
     if (FT == 0) {
         const int ntiles = (t.V + 31) / 32, ngroups = (Fpad / 32 + kMfmaWaves - 1) / kMfmaWaves;
         const unsigned mgrid = (unsigned)(((ntiles + 7) / 8) * 8 * ngroups);
-        skin_mfma_kernel<<<mgrid, 64 * kMfmaWaves, 0, stream>>>(t, F, Fpad, ntiles, featT, A_dst, out_vertices);
+        if (lbs_use_split(tb, FT)) {
+            const int K16 = k16_of(t.KB);
+            split_features_kernel<<<Fpad, 64, 0, stream>>>(t.KB, K16, F, Fpad, featT,
+                                                          static_cast<const unsigned *>(t.blend_split), featH, fscale);
+            skin_f16_kernel<<<mgrid, 64 * kMfmaWaves, 0, stream>>>(t, F, Fpad, ntiles, K16, featH, fscale, A_dst,
+                                                                   out_vertices);
+        } else {
+            skin_mfma_kernel<<<mgrid, 64 * kMfmaWaves, 0, stream>>>(t, F, Fpad, ntiles, featT, A_dst, out_vertices);
+        }
         return check_launch("amav_lbs_forward");
     }
     const int nchunks = (t.V + 255) / 256;

@@ -314,7 +314,23 @@ def body_tables_struct(tables: dict) -> BodyTables:
         setattr(t, k, _contig(tables[k], k).data_ptr())
     for k in ("parents", "skin_idx"):
         setattr(t, k, _contig(tables[k], k, torch.int32).data_ptr())
+    split = tables.get("blend_split")
+    t.blend_split = None if split is None else _contig(split, "blend_split", torch.uint8).data_ptr()
     return t
+
+
+def lbs_prepare_blend_split(tables: dict):
+    """-> uint8 device buffer: the blend table as two scaled fp16 parts in MFMA fragment order (include/amav.h,
+    amav_lbs_prepare_blend_split).  Put it into the tables dict as "blend_split": lbs_forward then runs the blend product
+    on the 16-bit matrix pipe."""
+    ts = body_tables_struct({k: v for k, v in tables.items() if k != "blend_split"})
+    nbytes = _lib.lib().amav_lbs_blend_split_bytes(ctypes.byref(ts))
+    if nbytes == 0:
+        raise AmavError("amav_lbs_blend_split_bytes rejected the tables: " + _lib.lib().amav_last_error().decode())
+    out = torch.empty(nbytes, dtype=torch.uint8, device=tables["blend"].device)
+    check(_lib.lib().amav_lbs_prepare_blend_split(ctypes.byref(ts), out.data_ptr(), nbytes, _stream()),
+          "amav_lbs_prepare_blend_split")
+    return out
 
 
 def lbs_forward(tables: dict, full_pose, coeffs, want_transforms=False):

@@ -177,7 +177,17 @@ typedef struct amav_body_tables {
     const int32_t *parents;
     const int32_t *skin_idx;
     const float *skin_w;
+    const void *blend_split; /* amav_lbs_prepare_blend_split's buffer, or NULL (the blend product then runs on fp32 MFMA) */
 } amav_body_tables;
+
+/* The blend table as two fp16 parts (scaled by one power of two) in the fragment order of the 16-bit MFMA: with it
+ * amav_lbs_forward computes the [F, KB] x [KB, 3V] blend product as three fp16 partial products per fp32 product with
+ * fp32 accumulation (the fp32 result to 2^-22, 3x faster than on fp32 MFMA; every frame's features get their own
+ * power-of-two scale).  Prepare once per model into a 256-byte aligned device buffer of amav_lbs_blend_split_bytes and
+ * put its address into tables->blend_split (`blend` must stay valid too: short batches use it).  AMAV_LBS=f32 in the
+ * environment ignores blend_split. */
+size_t amav_lbs_blend_split_bytes(const amav_body_tables *tables);
+int amav_lbs_prepare_blend_split(const amav_body_tables *tables, void *out_dev, size_t out_bytes, void *stream);
 
 size_t amav_lbs_workspace_bytes(int num_frames, const amav_body_tables *tables);
 /* full_pose [F, J*3] axis-angle (pose_mean already added), coeffs [F, n_coeff] (betas then expression).

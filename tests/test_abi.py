@@ -49,7 +49,7 @@ def test_struct_layouts_match_the_header(lib):
             fields += [re.sub(r"\[.*\]", "", f).strip(" *") for f in decl.split(None, 1)[1].replace("*", " ").split(",")]
     fields = [f.split()[-1] if " " in f else f for f in fields]
     assert [f for f, _ in _lib.RasterArgs._fields_] == fields
-    assert ctypes.sizeof(_lib.Attr) == 24 and ctypes.sizeof(_lib.BodyTables) == 16 + 7 * 8
+    assert ctypes.sizeof(_lib.Attr) == 24 and ctypes.sizeof(_lib.BodyTables) == 16 + 8 * 8
 
 
 def test_version_and_error_reporting(lib):
