@@ -574,8 +574,10 @@ def cpu_baseline_and_parity(renderer, cfg, tokens, smpl, cam, step_outputs, n_fr
     # stage-by-stage parity on identical inputs
     gpu_packed, gpu_rgba = (t[:n_frames].cpu() for t in step_outputs)
     gpu_g = renderer.unpack_gaussians(gpu_packed)
-    with torch.no_grad():  # the unfused product entry point of the same stage (Renderer.get_smpl_vertices)
-        gpu_pts = renderer.get_smpl_vertices({k: v[:, :n_frames] for k, v in smpl.items()}).cpu()
+    with torch.no_grad():  # the unfused product entry point of the same stage (Renderer.get_smpl_vertices), on the
+        # WHOLE shard: the frame count selects the LBS kernel (> 16 frames: the split-product MFMA kernel), and the decode
+        # check below needs the points the timed step itself used
+        gpu_pts = renderer.get_smpl_vertices(smpl)[:n_frames].cpu()
     g_on_gpu_pts = o_tri.decode_gaussians(params, planes, gpu_pts, sp["transl"].reshape(-1, 3), cfg.radius)
     ref_img, ref_alpha, ref_unstable = o_rast.render_batch({k: v.contiguous() for k, v in gpu_g.items()}, K, E,
                                                            cfg.image_size, full=True)
