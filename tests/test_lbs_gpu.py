@@ -83,6 +83,25 @@ def test_split_product_kernel_matches_the_fp32_mfma_kernel(F, scale):
     assert torch.equal(one[:17], v16[:17]) or (one[:17] - v16[:17]).abs().max() <= 1e-7
 
 
+def test_split_product_kernel_handles_zero_and_huge_features():
+    """A frame whose features are all zero (rest pose, zero shape) gets scale exponent 0 and returns the template; frames
+    with very large shape coefficients next to it keep their own scale."""
+    from audio_motion_avatar_amd import ops
+
+    F = 40
+    pose, coeffs = random_pose(5, F, scale=0.3)
+    pose[0], coeffs[0] = 0.0, 0.0
+    coeffs[1] *= 3e3
+    verts = ops.lbs_forward(body().device_tables(), pose.cuda(), coeffs.cuda()).cpu()
+    v64, _, _ = oracle_verts(pose, coeffs, torch.float64)
+    assert torch.isfinite(verts).all()
+    m = body().oracle_arrays(torch.float32)
+    if m["pose_mean"].abs().max() == 0:  # rest pose + zero shape: the template itself
+        assert (verts[0] - m["v_template"]).abs().max() <= 1e-6
+    rel = (verts.double() - v64).abs().amax(dim=(1, 2)) / v64.abs().amax(dim=(1, 2)).clamp_min(1.0)
+    assert rel.max() <= TOL
+
+
 def test_split_product_kernel_is_reproducible():
     """Regression: a first version of skin_f16_kernel kept its prefetch registers in lambda-captured arrays, which the
     compiler demoted to scratch memory and reloaded into the registers the in-flight MFMAs were still reading -- one
