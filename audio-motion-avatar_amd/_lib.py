@@ -108,6 +108,13 @@ SIGNATURES = {
     "amav_subm_pair_gemm": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                            c_float_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_float_p,
                                            c_float_p, ctypes.c_void_p]),
+    "amav_subm_weights_split_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "amav_subm_prepare_weights_split": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_float_p, ctypes.c_void_p,
+                                                       ctypes.c_size_t, ctypes.c_void_p]),
+    "amav_subm_pair_gemm_split": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                 ctypes.c_int64, c_float_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                 ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_float_p,
+                                                 ctypes.c_void_p]),
     "amav_subm_pair_sum": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, c_float_p, ctypes.c_void_p,
                                           c_float_p, c_float_p, ctypes.c_void_p]),
     "amav_patch_attention": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_float_p,

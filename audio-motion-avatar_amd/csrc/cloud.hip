@@ -21,7 +21,9 @@
 //   amav_bn_gelu           BatchNorm(eval) + GELU                                                (Embedding, Unpooling)
 //   amav_unpool_merge      skip = GELU(BN(x)); sum = skip + up[cluster]                        (SerializedUnpooling)
 //   amav_rows_norm         s = base + LN_a(x) (or base + x); n = LN_b(s): the residual + LayerNorm passes of a Block
+#include <algorithm>
 #include <climits>
+#include <cmath>
 
 #include "amav_common.h"
 
@@ -272,6 +274,169 @@ __global__ __launch_bounds__(256) void pair_gemm_kernel(const float *__restrict_
         if (p < p_end) {
 #pragma unroll
             for (int a = 0; a < NACC; ++a) products[(size_t)p * Cout + n0 + 32 * a + c] = acc[a][t];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same gather-GEMM on the 16-bit matrix pipe (split-product arithmetic): features and weights
+// as two fp16 parts each, (x 2^e = h1 + h2), three partial products per fp32 product on v_mfma_f32_32x32x16_f16 with fp32
+// accumulation -- the fp32 product to 2^-22 at a third of the matrix time.  Scaling (exact powers of two): the weights
+// by one exponent from their largest magnitude (static: subm_weights_split_kernel writes it into the prepared buffer's
+// header), the features by one exponent from the largest |feature| of the call (feat_absmax_kernel -> `scratch`).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+constexpr size_t kSplitHeader = 256;  // prepared weights: [0] float largest |w|, [1] int scale exponent
+
+__device__ __forceinline__ int f16_scale_exp(float amax) {
+    if (!(amax > 0.f)) return 0;
+    return max(-100, min(100, 14 - ilogbf(amax)));
+}
+__device__ __forceinline__ void split2(float x, _Float16 &a, _Float16 &b) {
+    a = (_Float16)x;
+    b = (_Float16)__builtin_fmaf((float)a, -1.0f, x);
+}
+
+__global__ __launch_bounds__(256) void absmax_kernel(const float4 *__restrict__ x4, long long n4, unsigned *__restrict__ out) {
+    float m = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const float4 v = x4[i];
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    __shared__ float wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(out, __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
+}
+
+// weights [taps][cin][cout] fp32 -> [tap][cout / 32][cin / 16][part][lane half hh][column c][8 k] fp16: the B fragment of
+// lane (c, hh) for one (k-step, part) is 16 contiguous bytes, and a 32-row chunk of one 32-column block is 4 KB that
+// the kernel copies to LDS as is.  One thread per (tap, column block, k-step, hh, c).
+__global__ __launch_bounds__(256) void subm_weights_split_kernel(const float *__restrict__ w, int cin, int cout, long long items,
+                                                                 unsigned *__restrict__ hdr, _Float16 *__restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = f16_scale_exp(__uint_as_float(hdr[0]));
+    if (i == 0) reinterpret_cast<int *>(hdr)[1] = e;
+    if (i >= items) return;
+    const int c = (int)(i & 31), hh = (int)((i >> 5) & 1);
+    const long long rest = i >> 6;  // (tap * nblk + nb) * ksteps + ks
+    const int ksteps = cin / 16, nblk = cout / 32;
+    const int ks = (int)(rest % ksteps), nb = (int)((rest / ksteps) % nblk);
+    const long long tap = rest / ksteps / nblk;
+    const float scale = ldexpf(1.0f, e);
+    f16x8 p1, p2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 16 * ks + 8 * hh + j;
+        _Float16 a, b;
+        split2(w[(tap * cin + k) * cout + nb * 32 + c] * scale, a, b);
+        p1[j] = a, p2[j] = b;
+    }
+    _Float16 *dst = out + (rest * 2) * 512 + hh * 256 + c * 8;
+    *reinterpret_cast<f16x8 *>(dst) = p1;
+    *reinterpret_cast<f16x8 *>(dst + 512) = p2;
+}
+
+// grid (tiles of 128 pairs, cout / NT), 256 threads = 4 waves of 32 pairs x NT columns, as pair_gemm_kernel
+template <int NT>
+__global__ __launch_bounds__(256) void pair_gemm_f16_kernel(const float *__restrict__ feat, const int *__restrict__ pair_src,
+                                                            const int *__restrict__ tap_start,
+                                                            const int *__restrict__ tile_start, int taps,
+                                                            const void *__restrict__ wsplit,
+                                                            const unsigned *__restrict__ feat_amax,
+                                                            float *__restrict__ products, int Cin, int Cout) {
+    constexpr int NACC = NT / 32, KC = 32, LDA = KC + 8;  // A rows of 80 bytes: 16-byte fragment reads without conflicts
+    __shared__ _Float16 As[2][128 * LDA];                 // [part][pair][k]
+    __shared__ float4 Bs[NACC * 256];                     // [column block][k-step][part][hh][c][8 k], 4 KB per block
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, hh = lane >> 5;
+    int lo = 0, hi = taps;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (tile_start[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
+    }
+    const int tap = lo;
+    const int p0 = tap_start[tap] + ((int)blockIdx.x - tile_start[tap]) * 128, p_end = tap_start[tap + 1];
+    const int n0 = blockIdx.y * NT;
+    const int ea = f16_scale_exp(__uint_as_float(feat_amax[0]));
+    const int ew = reinterpret_cast<const int *>(wsplit)[1];
+    const float a_scale = ldexpf(1.0f, ea);
+    const int ksteps = Cin / 16, nblk = Cout / 32;
+    // this block's weights: column block n0 / 32 + a, all k-steps: 2 KB per k-step
+    const float4 *wb = reinterpret_cast<const float4 *>(static_cast<const char *>(wsplit) + kSplitHeader) +
+                       ((size_t)tap * nblk + n0 / 32) * ksteps * 128;
+
+    const int arow = tid >> 3, ak = (tid & 7) * 4;
+    const float *ap0 = feat + (size_t)pair_src[min(p0 + arow, p_end - 1)] * Cin + ak;
+    const float *ap1 = feat + (size_t)pair_src[min(p0 + arow + 32, p_end - 1)] * Cin + ak;
+    const float *ap2 = feat + (size_t)pair_src[min(p0 + arow + 64, p_end - 1)] * Cin + ak;
+    const float *ap3 = feat + (size_t)pair_src[min(p0 + arow + 96, p_end - 1)] * Cin + ak;
+    float4 a0, a1, a2, a3, b0, b1, b2, b3;  // named: no arrays behind the prefetch (see lbs.hip, skin_f16_kernel)
+#define AMAV_PGH_LOAD(k0_)                                                                   \
+    {                                                                                        \
+        a0 = *reinterpret_cast<const float4 *>(ap0 + (k0_));                                 \
+        a1 = *reinterpret_cast<const float4 *>(ap1 + (k0_));                                 \
+        a2 = *reinterpret_cast<const float4 *>(ap2 + (k0_));                                 \
+        a3 = *reinterpret_cast<const float4 *>(ap3 + (k0_));                                 \
+        const float4 *src_ = wb + (size_t)((k0_) / 16) * 128 + tid;                          \
+        b0 = src_[0];                                                                        \
+        if (NACC > 1) b1 = src_[(size_t)ksteps * 128];                                       \
+        if (NACC > 2) b2 = src_[(size_t)2 * ksteps * 128], b3 = src_[(size_t)3 * ksteps * 128]; \
+    }
+#define AMAV_PGH_STAGE_A(i_, v_)                                                     \
+    {                                                                                \
+        const float x_[4] = {v_.x, v_.y, v_.z, v_.w};                                \
+        f16x4 h1_, h2_;                                                              \
+        _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                           \
+            _Float16 u_, l_;                                                         \
+            split2(x_[e_] * a_scale, u_, l_);                                        \
+            h1_[e_] = u_, h2_[e_] = l_;                                              \
+        }                                                                            \
+        *reinterpret_cast<f16x4 *>(&As[0][(arow + 32 * (i_)) * LDA + ak]) = h1_;     \
+        *reinterpret_cast<f16x4 *>(&As[1][(arow + 32 * (i_)) * LDA + ak]) = h2_;     \
+    }
+    f32x16 acc[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc[a][t] = 0.f;
+
+    AMAV_PGH_LOAD(0)
+    for (int k0 = 0; k0 < Cin; k0 += KC) {
+        AMAV_PGH_STAGE_A(0, a0) AMAV_PGH_STAGE_A(1, a1) AMAV_PGH_STAGE_A(2, a2) AMAV_PGH_STAGE_A(3, a3)
+        Bs[tid] = b0;
+        if (NACC > 1) Bs[256 + tid] = b1;
+        if (NACC > 2) Bs[512 + tid] = b2, Bs[768 + tid] = b3;
+        __syncthreads();
+        if (k0 + KC < Cin) AMAV_PGH_LOAD(k0 + KC)
+        const _Float16 *al = &As[0][(wave * 32 + c) * LDA + 8 * hh];
+        const _Float16 *bl = reinterpret_cast<const _Float16 *>(Bs) + hh * 256 + c * 8;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const f16x8 h1 = *reinterpret_cast<const f16x8 *>(al + 16 * s);
+            const f16x8 h2 = *reinterpret_cast<const f16x8 *>(al + 128 * LDA + 16 * s);
+#pragma unroll
+            for (int a = 0; a < NACC; ++a) {
+                // column block a, k-step s, part p at (a * 4 + s * 2 + p) * 512 halfs
+                const f16x8 g1 = *reinterpret_cast<const f16x8 *>(bl + (a * 4 + s * 2 + 0) * 512);
+                const f16x8 g2 = *reinterpret_cast<const f16x8 *>(bl + (a * 4 + s * 2 + 1) * 512);
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h2, g1, acc[a], 0, 0, 0);  // small terms first
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h1, g2, acc[a], 0, 0, 0);
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h1, g1, acc[a], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+#undef AMAV_PGH_LOAD
+#undef AMAV_PGH_STAGE_A
+    const float unscale = ldexpf(1.0f, -(ea + ew));
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int p = p0 + wave * 32 + (t & 3) + 8 * (t >> 2) + 4 * hh;
+        if (p < p_end) {
+#pragma unroll
+            for (int a = 0; a < NACC; ++a) products[(size_t)p * Cout + n0 + 32 * a + c] = acc[a][t] * unscale;
         }
     }
 }
@@ -629,6 +794,66 @@ extern "C" int amav_subm_pair_gemm(int64_t pairs, int tiles, int taps, int cin, 
     else
         cloud::pair_gemm_kernel<32><<<grid, 256, 0, stream>>>(feat, pair_src, tap_start, tile_start, taps, weights, products, cin, cout);
     return check_launch("amav_subm_pair_gemm");
+}
+
+static size_t subm_split_bytes(int taps, int cin, int cout) {
+    return cloud::kSplitHeader + (size_t)taps * cin * cout * 2 * sizeof(_Float16);
+}
+
+extern "C" size_t amav_subm_weights_split_bytes(int taps, int cin, int cout) {
+    if (taps <= 0 || cin <= 0 || cin % 32 || cout <= 0 || cout % 32) return 0;
+    return subm_split_bytes(taps, cin, cout);
+}
+
+extern "C" int amav_subm_prepare_weights_split(int taps, int cin, int cout, const float *weights, void *out,
+                                               size_t out_bytes, void *stream_) {
+    AMAV_REQUIRE(taps > 0 && cin > 0 && cin % 32 == 0 && cout > 0 && cout % 32 == 0,
+                 "amav_subm_prepare_weights_split: taps=%d, channels must be multiples of 32 (C_in %d, C_out %d)", taps, cin, cout);
+    AMAV_REQUIRE(weights && out && aligned16(weights) && (reinterpret_cast<uintptr_t>(out) & 255) == 0,
+                 "amav_subm_prepare_weights_split: NULL / misaligned pointer (out: 256 bytes)");
+    if (out_bytes < subm_split_bytes(taps, cin, cout))
+        return fail(AMAV_ERR_WORKSPACE, "amav_subm_prepare_weights_split: buffer %zu < required %zu", out_bytes,
+                    subm_split_bytes(taps, cin, cout));
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    unsigned *hdr = static_cast<unsigned *>(out);
+    AMAV_REQUIRE(hipMemsetAsync(hdr, 0, cloud::kSplitHeader, stream) == hipSuccess, "amav_subm_prepare_weights_split: memset failed");
+    const long long n4 = (long long)taps * cin * cout / 4;
+    cloud::absmax_kernel<<<(unsigned)std::min<long long>((n4 + 255) / 256, 256), 256, 0, stream>>>(
+        reinterpret_cast<const float4 *>(weights), n4, hdr);
+    const long long items = (long long)taps * (cout / 32) * (cin / 16) * 64;
+    cloud::subm_weights_split_kernel<<<blocks_for(items), 256, 0, stream>>>(
+        weights, cin, cout, items, hdr, reinterpret_cast<_Float16 *>(static_cast<char *>(out) + cloud::kSplitHeader));
+    return check_launch("amav_subm_prepare_weights_split");
+}
+
+extern "C" int amav_subm_pair_gemm_split(int64_t pairs, int tiles, int taps, int cin, int cout, int64_t n_rows,
+                                         const float *feat, const int32_t *pair_src, const int32_t *tap_start,
+                                         const int32_t *tile_start, const void *weights_split, void *scratch16,
+                                         float *products, void *stream_) {
+    AMAV_REQUIRE(pairs > 0 && pairs < INT_MAX && tiles > 0 && taps > 0 && n_rows > 0,
+                 "amav_subm_pair_gemm_split: bad sizes pairs=%lld tiles=%d taps=%d rows=%lld", (long long)pairs, tiles, taps,
+                 (long long)n_rows);
+    AMAV_REQUIRE(cin > 0 && cin % 32 == 0 && cout > 0 && cout % 32 == 0,
+                 "amav_subm_pair_gemm_split: channels must be multiples of 32 (C_in %d, C_out %d)", cin, cout);
+    AMAV_REQUIRE(feat && pair_src && tap_start && tile_start && weights_split && scratch16 && products,
+                 "amav_subm_pair_gemm_split: NULL pointer");
+    AMAV_REQUIRE(aligned16(feat) && aligned16(weights_split) && aligned16(products) && aligned16(scratch16),
+                 "amav_subm_pair_gemm_split: buffers must be 16-byte aligned");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    unsigned *amax = static_cast<unsigned *>(scratch16);
+    AMAV_REQUIRE(hipMemsetAsync(amax, 0, 16, stream) == hipSuccess, "amav_subm_pair_gemm_split: memset failed");
+    const long long n4 = (long long)n_rows * cin / 4;
+    cloud::absmax_kernel<<<(unsigned)std::min<long long>((n4 + 255) / 256, 256), 256, 0, stream>>>(
+        reinterpret_cast<const float4 *>(feat), n4, amax);
+    const int nt = cout % 128 == 0 ? 128 : (cout % 64 == 0 ? 64 : 32);
+    const dim3 grid((unsigned)tiles, (unsigned)(cout / nt));
+    if (nt == 128)
+        cloud::pair_gemm_f16_kernel<128><<<grid, 256, 0, stream>>>(feat, pair_src, tap_start, tile_start, taps, weights_split, amax, products, cin, cout);
+    else if (nt == 64)
+        cloud::pair_gemm_f16_kernel<64><<<grid, 256, 0, stream>>>(feat, pair_src, tap_start, tile_start, taps, weights_split, amax, products, cin, cout);
+    else
+        cloud::pair_gemm_f16_kernel<32><<<grid, 256, 0, stream>>>(feat, pair_src, tap_start, tile_start, taps, weights_split, amax, products, cin, cout);
+    return check_launch("amav_subm_pair_gemm_split");
 }
 
 extern "C" int amav_subm_pair_sum(int64_t n, int taps, int cout, const float *products, const int32_t *pair_of,

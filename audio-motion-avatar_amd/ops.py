@@ -711,6 +711,40 @@ def subm_pair_gemm(feat, pair_src, tap_start, tile_start, tiles, weights):
     return products
 
 
+def subm_prepare_weights_split(weights):
+    """weights [taps,C_in,C_out] fp32 -> uint8 device buffer: two scaled fp16 parts in MFMA fragment order (include/amav.h,
+    amav_subm_prepare_weights_split), the operand of subm_pair_gemm(..., weights_split=...)."""
+    weights = _contig(weights, "weights")
+    taps, cin, cout = weights.shape
+    nbytes = _lib.lib().amav_subm_weights_split_bytes(taps, cin, cout)
+    if nbytes == 0:
+        raise AmavError(f"subm_prepare_weights_split: channels must be multiples of 32, got {cin} -> {cout}")
+    out = torch.empty(nbytes, dtype=torch.uint8, device=weights.device)
+    check(_lib.lib().amav_subm_prepare_weights_split(taps, cin, cout, weights.data_ptr(), out.data_ptr(), nbytes, _stream()),
+          "amav_subm_prepare_weights_split")
+    return out
+
+
+def subm_pair_gemm_split(feat, pair_src, tap_start, tile_start, tiles, weights_split, taps, cout):
+    """subm_pair_gemm on the 16-bit matrix pipe: weights_split from subm_prepare_weights_split ([taps,C_in,cout])."""
+    feat = _contig(feat, "feat")
+    pair_src = _contig(pair_src, "pair_src", torch.int32)
+    tap_start, tile_start = _contig(tap_start, "tap_start", torch.int32), _contig(tile_start, "tile_start", torch.int32)
+    n, cin = feat.shape
+    if tap_start.shape != (taps + 1,) or tile_start.shape != (taps + 1,):
+        raise AmavError("subm_pair_gemm_split: shapes do not match")
+    need = _lib.lib().amav_subm_weights_split_bytes(taps, cin, cout)
+    if need == 0 or _need(weights_split, "weights_split", torch.uint8).numel() != need:
+        raise AmavError("subm_pair_gemm_split: weights_split was not prepared for these shapes")
+    products = torch.empty(pair_src.shape[0], cout, device=feat.device)
+    scratch = torch.empty(4, dtype=torch.int32, device=feat.device)
+    check(_lib.lib().amav_subm_pair_gemm_split(pair_src.shape[0], int(tiles), taps, cin, cout, n, feat.data_ptr(),
+                                               pair_src.data_ptr(), tap_start.data_ptr(), tile_start.data_ptr(),
+                                               weights_split.data_ptr(), scratch.data_ptr(), products.data_ptr(),
+                                               _stream()), "amav_subm_pair_gemm_split")
+    return products
+
+
 def subm_pair_sum(products, pair_of, bias=None):
     """products [P,C_out], pair_of int32 [n,taps] (-1: no voxel) -> [n,C_out] = bias + sum over taps in tap order."""
     products, pair_of = _contig(products, "products"), _contig(pair_of, "pair_of", torch.int32)

@@ -16,6 +16,7 @@ convolution (only the voxel pairs that exist) + an ordered sum, one attention la
 serialised operators are HIP kernels (csrc/cloud.hip); Linear / LayerNorm / sort / prefix sums are torch library calls
 on the same stream.  Inference only.
 """
+import os
 from types import SimpleNamespace
 
 import numpy as np
@@ -41,6 +42,7 @@ class SubMConv3d(nn.Module):
         nn.init.kaiming_uniform_(self.weight.view(out_channels, -1), a=5 ** 0.5)
         self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
         self._flat = None
+        self._split = None  # (the tap_weights() tensor it was made from, its fp16 x 2 form)
 
     def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
         w = state_dict.get(prefix + "weight")
@@ -64,7 +66,14 @@ class SubMConv3d(nn.Module):
         pad = -self.in_channels % 32
         if pad:
             feat = F.pad(feat, (0, pad))
-        products = ops.subm_pair_gemm(feat, pairs.pair_src, pairs.tap_start, pairs.tile_start, pairs.tiles, self.tap_weights())
+        w = self.tap_weights()
+        if os.environ.get("AMAV_SUBM", "split") == "f32":  # the fp32 MFMA form
+            products = ops.subm_pair_gemm(feat, pairs.pair_src, pairs.tap_start, pairs.tile_start, pairs.tiles, w)
+        else:  # three fp16 partial products per fp32 product (csrc/cloud.hip, pair_gemm_f16_kernel)
+            if self._split is None or self._split[0] is not w:
+                self._split = (w, ops.subm_prepare_weights_split(w))
+            products = ops.subm_pair_gemm_split(feat.contiguous(), pairs.pair_src, pairs.tap_start, pairs.tile_start,
+                                                pairs.tiles, self._split[1], w.shape[0], w.shape[2])
         return ops.subm_pair_sum(products, pairs.pair_of, None if self.bias is None else self.bias.detach())
 
 

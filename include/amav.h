@@ -346,6 +346,12 @@ int amav_add_layernorm(int64_t rows, int dim, int64_t rows_per_batch, const floa
  *                       int32), pair p of tap t: products[p] [cout] = feat[pair_src[p]] [cin] x weights[t] [cin][cout]
  *                       (weights [taps,cin,cout]); tile_start [taps+1] int32 = prefix sum of ceil(pairs of tap / 128),
  *                       tiles = its last entry; cin, cout multiples of 32.  fp32 MFMA.
+ * amav_subm_pair_gemm_split  the same products as three fp16 partial products per fp32 product on the 16-bit MFMA pipe
+ *                       (fp32 accumulation, the fp32 result to 2^-22): weights_split = the buffer of
+ *                       amav_subm_prepare_weights_split (weights as two fp16 parts scaled by one power of two, in MFMA
+ *                       fragment order; prepare once per layer into 256-byte aligned memory of
+ *                       amav_subm_weights_split_bytes); feat [n_rows, cin] is scaled by one power of two from its largest
+ *                       magnitude, measured by a pre-pass into scratch16 (16 bytes of device memory).
  * amav_subm_pair_sum    out [n,cout] = bias + sum over taps (ascending) of products[pair_of[i][tap]] (pair_of [n,taps]
  *                       int32, -1: no voxel); bias may be NULL.
  * amav_patch_attention  out [n, heads*head_dim] = softmax(q k^T * scale) v inside patches of a serialised order.
@@ -372,6 +378,13 @@ int amav_cloud_neighbors(int64_t n, int ksize, const int32_t *grid_dev, const in
 int amav_subm_pair_gemm(int64_t pairs, int tiles, int taps, int cin, int cout, const float *feat_dev,
                         const int32_t *pair_src_dev, const int32_t *tap_start_dev, const int32_t *tile_start_dev,
                         const float *weights_dev, float *products_dev, void *stream);
+size_t amav_subm_weights_split_bytes(int taps, int cin, int cout);
+int amav_subm_prepare_weights_split(int taps, int cin, int cout, const float *weights_dev, void *out_dev,
+                                    size_t out_bytes, void *stream);
+int amav_subm_pair_gemm_split(int64_t pairs, int tiles, int taps, int cin, int cout, int64_t n_rows,
+                              const float *feat_dev, const int32_t *pair_src_dev, const int32_t *tap_start_dev,
+                              const int32_t *tile_start_dev, const void *weights_split_dev, void *scratch16_dev,
+                              float *products_dev, void *stream);
 int amav_subm_pair_sum(int64_t n, int taps, int cout, const float *products_dev, const int32_t *pair_of_dev,
                        const float *bias_dev, float *out_dev, void *stream);
 int amav_patch_attention(int patches, int max_patch, int heads, int head_dim, const float *qkv_dev,

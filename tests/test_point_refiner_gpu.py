@@ -94,6 +94,34 @@ def test_subm_conv_matches_oracle(cin, cout, ksize, F, N):
     assert level.pairs(ksize).count == int((level.neighbors(ksize) >= 0).sum())
 
 
+@pytest.mark.parametrize("scale", [1.0, 1e-4, 3e3])
+def test_subm_conv_split_products_match_the_fp32_mfma_form(monkeypatch, scale):
+    """Default: three fp16 partial products per fp32 product (pair_gemm_f16_kernel), features scaled by the power of two
+    of the call's largest magnitude; AMAV_SUBM=f32: the fp32 MFMA kernel.  Same result to fp32 rounding at any scale."""
+    ops, pt = _mods()
+    F, N, cin, cout, ksize = 2, 800, 128, 128, 3
+    pts = _clouds(11, F, N)
+    n = F * N
+    cloud_of = torch.arange(F, dtype=torch.int32).repeat_interleave(N).cuda()
+    grid, depth = ops.cloud_voxelize(pts.reshape(n, 3).cuda(), cloud_of, F)
+    level = pt.Level(grid, cloud_of, depth, np.full(F, N), ops.cloud_codes(grid, cloud_of, depth))
+    gen = torch.Generator().manual_seed(9)
+    feat = (torch.randn(n, cin, generator=gen) * scale).cuda()
+    feat[5] *= 50.0  # one outlier row sets the call's scale; the other rows keep their precision
+    conv = pt.SubMConv3d(cin, cout, ksize, bias=True).cuda()
+    split = conv(feat, level)
+    assert torch.equal(conv(feat, level), split)  # reproducible
+    monkeypatch.setenv("AMAV_SUBM", "f32")
+    plain = conv(feat, level)
+    ref = float(plain.abs().max())
+    assert float((split - plain).abs().max()) <= 4e-6 * ref
+    with torch.no_grad():
+        conv.weight.mul_(0.5)  # the prepared weights follow in-place updates
+    monkeypatch.delenv("AMAV_SUBM")
+    bias = conv.bias.detach()
+    assert float((conv(feat, level) - bias - 0.5 * (split - bias)).abs().max()) <= 4e-6 * ref
+
+
 @pytest.mark.parametrize("heads,dim,counts,patch", [(4, 64, [1300, 512, 70], 512), (2, 32, [300, 130], 128),
                                                     (2, 16, [257, 33, 64], 128), (1, 64, [5], 512)])
 def test_patch_attention_matches_oracle(heads, dim, counts, patch):
