@@ -64,6 +64,42 @@ def test_version_and_error_reporting(lib):
     assert lib.amav_points_gather(1, 1, 1, None, None, None, None) == -1
 
 
+def test_split_product_entry_points_validate_before_touching_the_device(lib):
+    """Argument checks and size queries of the split-product entry points run on the host (no launch on a bad call)."""
+    import ctypes
+
+    from audio_motion_avatar_amd import _lib
+
+    fake = 4096  # a non-NULL, 16-byte aligned address that is never dereferenced on these paths
+    # operand split: k must be a multiple of 8, formats 0 / 1, fp16 exponent in range
+    assert lib.amav_split_operand(4, 12, fake, 12, 0, 0, 0, fake, None) == -1 and b"multiple of 8" in lib.amav_last_error()
+    assert lib.amav_split_operand(4, 16, fake, 16, 0, 7, 0, fake, None) == -1 and b"format" in lib.amav_last_error()
+    assert lib.amav_split_operand(4, 16, fake, 16, 0, 1, 500, fake, None) == -1
+    assert lib.amav_split_operand(4, 16, None, 16, 0, 0, 0, fake, None) == -1
+    # GEGLU / residual-LayerNorm: exactly one of the fp32 and the split output
+    assert lib.amav_geglu(4, 16, fake, 32, None, fake, fake, 0, None) == -1 and b"exactly one" in lib.amav_last_error()
+    assert lib.amav_geglu(4, 16, fake, 32, None, None, None, 0, None) == -1
+    assert lib.amav_add_layernorm(4, 512, 4, None, None, None, fake, fake, fake, fake, 1e-5, fake, fake, 0, 0, None) == -1
+    assert b"exactly one" in lib.amav_last_error()
+    assert lib.amav_add_layernorm(4, 512, 4, None, fake, None, fake, fake, fake, fake, 1e-5, fake, None, 0, 0, None) == -1
+    assert b"add_bias without add" in lib.amav_last_error()
+    # attention: all three bounds or none
+    assert lib.amav_selfattn_forward_bounded(1, 64, 1, 64, fake, fake, fake, 64, fake, 64, 0.125, 1.0, 0.0, 1.0, fake, 1 << 30,
+                                             None) == -1
+    assert b"all three bounds" in lib.amav_last_error()
+    # prepared operands: sizes = header + two fp16 parts of every entry
+    assert lib.amav_subm_weights_split_bytes(27, 64, 128) == 256 + 27 * 64 * 128 * 2 * 2
+    assert lib.amav_subm_weights_split_bytes(27, 48, 128) == 0 and lib.amav_subm_weights_split_bytes(0, 64, 64) == 0
+    assert lib.amav_subm_prepare_weights_split(27, 64, 128, fake, fake, 16, None) == -3        # AMAV_ERR_WORKSPACE
+    t = _lib.BodyTables()
+    t.num_verts, t.num_joints, t.num_coeffs, t.skin_k = 10475, 55, 20, 4
+    for name in ("v_template", "blend", "j_template", "j_dirs", "parents", "skin_idx", "skin_w"):
+        setattr(t, name, fake)
+    kb = 20 + 54 * 9  # 506 blend rows, padded to 512: 32 k-steps of 16 per 32-vertex tile
+    assert lib.amav_lbs_blend_split_bytes(ctypes.byref(t)) == 256 + 328 * 32 * 2 * 3 * 512 * 2 and kb == 506
+    assert lib.amav_lbs_prepare_blend_split(ctypes.byref(t), fake + 8, 1 << 30, None) == -1    # not 256-byte aligned
+
+
 def test_product_refuses_to_run_without_a_device():
     """No CPU fallback: a CPU tensor is an error, not a slow path."""
     import torch
