@@ -318,7 +318,7 @@ class BodyModel(torch.nn.Module):
         if self._blend.is_cuda:
             # the blend table as two fp16 parts for the 16-bit matrix pipe (csrc/lbs.hip, skin_f16_kernel), built once
             # per device placement of the table
-            key = (self._blend.data_ptr(), self._blend._version)
+            key = (self._blend.data_ptr(), ops.tensor_version(self._blend))
             if getattr(self, "_blend_split", None) is None or self._blend_split[0] != key:
                 from . import ops
 

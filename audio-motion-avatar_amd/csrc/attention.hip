@@ -961,7 +961,7 @@ extern "C" int amav_selfattn_forward_bounded(int B, int S, int H, int D, const f
             if (bounded) {
                 hdr = nullptr;  // the kernels scale from `given`
             } else {            // measure max |q|, |k|, |v|
-                AMAV_REQUIRE(hipMemsetAsync(hdr, 0, 16, stream) == hipSuccess, "amav_selfattn_forward: header memset failed");
+                AMAV_REQUIRE(zero_async(hdr, 16, stream) == hipSuccess, "amav_selfattn_forward: header clear failed");
                 const long long rows = (long long)B * S;
                 const long long quads = rows * (H * attn::kD / 4);
                 attn::absmax_kernel<<<(unsigned)std::min<long long>((quads + 255) / 256, 512), 256, 0, stream>>>(

@@ -816,7 +816,7 @@ extern "C" int amav_subm_prepare_weights_split(int taps, int cin, int cout, cons
                     subm_split_bytes(taps, cin, cout));
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     unsigned *hdr = static_cast<unsigned *>(out);
-    AMAV_REQUIRE(hipMemsetAsync(hdr, 0, cloud::kSplitHeader, stream) == hipSuccess, "amav_subm_prepare_weights_split: memset failed");
+    AMAV_REQUIRE(zero_async(hdr, cloud::kSplitHeader, stream) == hipSuccess, "amav_subm_prepare_weights_split: header clear failed");
     const long long n4 = (long long)taps * cin * cout / 4;
     cloud::absmax_kernel<<<(unsigned)std::min<long long>((n4 + 255) / 256, 256), 256, 0, stream>>>(
         reinterpret_cast<const float4 *>(weights), n4, hdr);
@@ -841,7 +841,7 @@ extern "C" int amav_subm_pair_gemm_split(int64_t pairs, int tiles, int taps, int
                  "amav_subm_pair_gemm_split: buffers must be 16-byte aligned");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     unsigned *amax = static_cast<unsigned *>(scratch16);
-    AMAV_REQUIRE(hipMemsetAsync(amax, 0, 16, stream) == hipSuccess, "amav_subm_pair_gemm_split: memset failed");
+    AMAV_REQUIRE(zero_async(amax, 16, stream) == hipSuccess, "amav_subm_pair_gemm_split: scratch clear failed");
     const long long n4 = (long long)n_rows * cin / 4;
     cloud::absmax_kernel<<<(unsigned)std::min<long long>((n4 + 255) / 256, 256), 256, 0, stream>>>(
         reinterpret_cast<const float4 *>(feat), n4, amax);

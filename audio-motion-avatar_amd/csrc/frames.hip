@@ -382,7 +382,7 @@ extern "C" int amav_frames_pack_tiles(int F, int H, int W, const float *rgba, co
     const unsigned bgw = pack_bg(bg_host3);
     int *header = static_cast<int *>(wire), *frame_counts = header + kWireHeaderInts, *offsets = frame_counts + F;
     if (zero_async(header, (size_t)kWireHeaderInts * 4, stream) != hipSuccess)
-        return fail(AMAV_ERR_LAUNCH, "amav_frames_pack_tiles: hipMemsetAsync failed");
+        return fail(AMAV_ERR_LAUNCH, "amav_frames_pack_tiles: header clear failed");
     const float4 *px = reinterpret_cast<const float4 *>(rgba);
     const unsigned grid = (unsigned)((tiles + 3) / 4);
     if (tile_hint)

@@ -672,7 +672,7 @@ extern "C" int amav_lbs_prepare_blend_split(const amav_body_tables *tb, void *ou
     const int KB = tb->num_coeffs + (tb->num_joints - 1) * 9, K16 = k16_of(KB);
     const long long ntiles = (tb->num_verts + 31) / 32;
     unsigned *hdr = static_cast<unsigned *>(out);
-    AMAV_REQUIRE(hipMemsetAsync(hdr, 0, kSplitHeaderBytes, stream) == hipSuccess, "amav_lbs_prepare_blend_split: memset failed");
+    AMAV_REQUIRE(zero_async(hdr, kSplitHeaderBytes, stream) == hipSuccess, "amav_lbs_prepare_blend_split: header clear failed");
     const long long n4 = ntiles * KB * 24;
     table_absmax_kernel<<<(unsigned)std::min<long long>((n4 + 255) / 256, 512), 256, 0, stream>>>(
         reinterpret_cast<const float4 *>(tb->blend), n4, hdr);
@@ -710,7 +710,7 @@ extern "C" int amav_lbs_forward(int F, const amav_body_tables *tb, const float *
     // reads kMfmaKPad zero rows past the table
     const size_t feat_rows = (size_t)t.KB + (FT ? 0 : kMfmaKPad);
     if ((Fpad != F || FT == 0) && zero_async(featT, feat_rows * Fpad * sizeof(float), stream) != hipSuccess)
-        return fail(AMAV_ERR_LAUNCH, "amav_lbs_forward: hipMemsetAsync failed");
+        return fail(AMAV_ERR_LAUNCH, "amav_lbs_forward: padding clear failed");
     float *A_dst = out_A ? out_A : A;
     joint_chain_kernel<<<F, 64, 0, stream>>>(t, F, Fpad, full_pose, coeffs, featT, A_dst);
     if (FT == 0) {

@@ -1184,7 +1184,7 @@ extern "C" int amav_rasterize_forward(const amav_raster_args *a, void *stream_) 
                         a->scales.frame_stride == a->means3d.frame_stride &&
                         a->colors.frame_stride == a->means3d.frame_stride;
     if (zero_async(p.buf.status, sizeof(Status), stream) != hipSuccess)
-        return fail(AMAV_ERR_LAUNCH, "amav_rasterize_forward: hipMemsetAsync failed");
+        return fail(AMAV_ERR_LAUNCH, "amav_rasterize_forward: status clear failed");
 
     if (packed)
         bin_kernel<true><<<F, 1024, bin_lds, stream>>>(p);

@@ -110,12 +110,14 @@ class FrameAllGather:
         else:
             self.capacity = None
             self.status = torch.zeros(1, dtype=torch.int32, device=device)
-            # differential unpack (width % 16 == 0): each dense buffer is reused every other step and ~80 % of an
-            # avatar frame is background, so only stored tiles and tiles the body moved out of are rewritten
+            # differential unpack: each dense buffer is reused every other step and ~80 % of an avatar frame is
+            # background, so only stored tiles and tiles the body moved out of are rewritten.  Frames outside that
+            # kernel's limits (width not a multiple of 16, or more tiles per frame than its LDS table holds, e.g.
+            # 3840 x 2160) take the full unpack
             from . import ops
 
             self.tile_state = ([ops.frames_tile_state(world_size, frames, height, width, device) for _ in range(2)]
-                               if width % 16 == 0 else [None, None])
+                               if ops.frames_delta_unpack_supported(height, width) else [None, None])
 
     # ---- sparse wire -------------------------------------------------------------------------------------------------
     def calibrate(self, rgba: torch.Tensor, headroom=1.1, tile_hint=None):

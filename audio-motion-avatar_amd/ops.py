@@ -17,6 +17,13 @@ GAUSS_STRIDE = 16   # floats per packed Gaussian record (AMAV_GAUSS_STRIDE)
 REC_XYZ, REC_OPACITY, REC_ROT, REC_SCALE, REC_COLOR = 0, 3, 4, 8, 12
 
 
+def tensor_version(t: torch.Tensor) -> int:
+    """Version counter of a tensor for "has it been modified in place" cache keys, or -1 for inference tensors (created
+    under torch.inference_mode(): they track no version -- reading `_version` raises -- and cannot be modified outside
+    it, so identity + storage address identify their contents)."""
+    return -1 if t.is_inference() else t._version
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -299,8 +306,21 @@ def frames_unpack_tiles(wire_all, num_buffers, F, H, W, capacity_tiles, out=None
     return out, status
 
 
+DELTA_UNPACK_MAX_TILES = 64 * 1024 // 4 - 16 * 128  # amav_frames_unpack_tiles_delta keeps (T + 16 * 128) ints in LDS
+
+
+def frames_delta_unpack_supported(H, W) -> bool:
+    """Whether amav_frames_unpack_tiles_delta accepts frames of this size (width a multiple of 16 and a per-frame tile
+    table that fits its 64 KiB of LDS: 14 336 tiles -- the reference's 1296 x 2304 frames have 11 664, a 3840 x 2160
+    frame 32 400)."""
+    return W % 16 == 0 and ((H + 15) // 16) * ((W + 15) // 16) <= DELTA_UNPACK_MAX_TILES
+
+
 def frames_tile_state(num_buffers, F, H, W, device):
     """Fresh per-tile state of a reusable dense output buffer for the differential unpack: every tile unknown (-1)."""
+    if not frames_delta_unpack_supported(H, W):
+        raise AmavError(f"frames_tile_state: {H}x{W} frames are outside the differential unpack's limits "
+                        "(use frames_unpack_tiles without `state`)")
     return torch.full((num_buffers * F * ((H + 15) // 16) * ((W + 15) // 16),), -1, dtype=torch.int32, device=device)
 
 

@@ -53,7 +53,7 @@ class SubMConv3d(nn.Module):
 
     def tap_weights(self):
         """[taps, C_in (padded to a multiple of 32), C_out]: one B operand per tap."""
-        ver = (self.weight._version, self.weight.data_ptr())
+        ver = (ops.tensor_version(self.weight), self.weight.data_ptr())
         if self._flat is None or self._flat[0] != ver:
             w = self.weight.detach().reshape(self.out_channels, -1, self.in_channels).permute(1, 2, 0)
             pad = -self.in_channels % 32
@@ -79,7 +79,7 @@ class SubMConv3d(nn.Module):
 
 def _bn_fold(bn):
     """BatchNorm1d in eval mode as (scale, shift)."""
-    ver = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version, bn.weight.data_ptr())
+    ver = tuple(ops.tensor_version(t) for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)) + (bn.weight.data_ptr(),)
     cached = getattr(bn, "_amav_fold", None)
     if cached is None or cached[0] != ver:
         scale = bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)

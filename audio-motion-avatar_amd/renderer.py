@@ -163,7 +163,7 @@ class Renderer(nn.Module):
         gd = self.gaussian_decoder
         layers = dict(xyz_layer=gd.xyz_layer, rotation_layer=gd.rotation_layer, scaling_layer=gd.scaling_layer,
                       opacity_layer=gd.opacity_layer, shs_layer=gd.shs_layer)
-        version = tuple((l.weight._version, l.bias._version, l.weight.data_ptr()) for l in layers.values())
+        version = tuple((ops.tensor_version(l.weight), ops.tensor_version(l.bias), l.weight.data_ptr()) for l in layers.values())
         if self._packed is None or self._packed[0] != version:
             heads = {k: (l.weight, l.bias) for k, l in layers.items()}
             self._packed = (version, ops.pack_head_weights(heads, self.cfg.triplane_feature_dim,
@@ -183,14 +183,15 @@ class Renderer(nn.Module):
         proj = ops.triplane_project(triplane_tokens, w_plane, self._plane_resolution(triplane_tokens))
         return ops.triplane_sample_decode(proj, points, transl, self.cfg.radius, w_point)
 
-    def gaussians_from_tokens(self, triplane_tokens, smpl_params, out=None, side_work=None):
+    def gaussians_from_tokens(self, triplane_tokens, smpl_params, out=None, side_work=None, window_plan=None):
         """renderer.py:127-181 as one fused stage: tokens [F,C,3R^2] + SMPL-X params -> packed Gaussians [F,N,16].
 
         Everything is enqueued on the calling stream: slab projection, camera set-up (`side_work`, an optional
         callable whose result is returned as a second value), LBS chain, then the sampling kernel with the densify +
         subset gather folded in.  (Round 1 ran the projection on a helper stream; measured worth nothing -- 1.148 vs
         1.137 ms per 250-frame step -- and a fork/join graph only hid the hipMemsetAsync replay fault described in
-        DESIGN.md section 1.)
+        DESIGN.md section 1.)  `window_plan`: the windowed upsampler's plan for exactly these frames (mask [F,g,g] per
+        plane); refined points that leave it raise _WindowTooSmall.
         """
         F = triplane_tokens.shape[0]
         w_plane, w_point = self._head_weights()
@@ -202,9 +203,8 @@ class Renderer(nn.Module):
             if self.cfg.densify_smplx_verts:
                 vertices = ops.points_gather(vertices, self._gather_idx)
             points = self.refine_points(triplane_tokens, vertices)
-            bounds = getattr(self, "_window_bounds", None)
-            if bounds is not None and not self.triplane_upsampler.windows_contain(
-                    bounds, points, self.cfg.triplane_resolution, self.cfg.radius):
+            if window_plan is not None and not self.triplane_upsampler.windows_contain(
+                    window_plan, points, self.cfg.triplane_resolution, self.cfg.radius):
                 raise _WindowTooSmall()
             packed = ops.triplane_sample_decode(proj, points, transl, self.cfg.radius, w_point, out=out)
         elif self.cfg.densify_smplx_verts:
@@ -215,7 +215,7 @@ class Renderer(nn.Module):
         return packed if side_work is None else (packed, side_result)
 
     def render_tokens(self, triplane_tokens, smpl_params, cam_params, chunks=1, workspaces=None, check_overflow=True,
-                      bg_color=None):
+                      bg_color=None, window_plan=None):
         """tokens [F,C,3R^2] + SMPL-X params [B,T,...] (B*T = F) + cameras -> (rgba [F,H,W,4], packed [F,N,16]).
 
         The body of forward() after the SMPL-X decoder.  With `chunks` > 1 the frames are split into that many
@@ -223,6 +223,7 @@ class Renderer(nn.Module):
         are memory- and latency-bound, so one group's rasterisation overlaps the next group's decode.
         `workspaces`: optional list of per-chunk RasterWorkspace objects (reused across calls; resized entries are
         written back).  With check_overflow=False the caller must check workspaces[i].status() itself.
+        `window_plan`: see gaussians_from_tokens (covers all F frames; every frame group checks its own slice of it).
         """
         F = triplane_tokens.shape[0]
         H, W = int(self.cfg.image_size[0]), int(self.cfg.image_size[1])
@@ -241,25 +242,29 @@ class Renderer(nn.Module):
         while len(self._chunk_streams) < chunks - 1:
             self._chunk_streams.append(torch.cuda.Stream(device=dev))
         used = []
-        for ci, (s, e) in enumerate(bounds):
-            st = cur if ci == 0 else self._chunk_streams[ci - 1]
-            if st is not cur:
-                st.wait_stream(cur)
-            with torch.cuda.stream(st):
-                sub = {k: v[s:e].unsqueeze(0) for k, v in flat.items()}
-                Kc, Ec = K[s:e].float(), E[s:e].float()
-                packed, camera = self.gaussians_from_tokens(
-                    triplane_tokens[s:e], sub, out=packed_all[s:e],
-                    side_work=lambda: ops.camera_from_intrinsics(Kc, Ec, H, W))
-                g = self.unpack_gaussians(packed)
-                out = render_batch(g, K[s:e].unsqueeze(0), E[s:e].unsqueeze(0), self.cfg, bg_color,
-                                   workspace=workspaces[ci], check_overflow=check_overflow, out_rgba=rgba[s:e],
-                                   return_workspace=True, camera=camera[:3])
-                workspaces[ci] = out[1]
-            used.append(st)
-        for st in used:
-            if st is not cur:
-                cur.wait_stream(st)
+        try:
+            for ci, (s, e) in enumerate(bounds):
+                st = cur if ci == 0 else self._chunk_streams[ci - 1]
+                if st is not cur:
+                    st.wait_stream(cur)
+                used.append(st)
+                with torch.cuda.stream(st):
+                    sub = {k: v[s:e].unsqueeze(0) for k, v in flat.items()}
+                    Kc, Ec = K[s:e].float(), E[s:e].float()
+                    plan = None if window_plan is None else [
+                        dict(w, mask=None if w["mask"] is None else w["mask"][s:e]) for w in window_plan]
+                    packed, camera = self.gaussians_from_tokens(
+                        triplane_tokens[s:e], sub, out=packed_all[s:e],
+                        side_work=lambda: ops.camera_from_intrinsics(Kc, Ec, H, W), window_plan=plan)
+                    g = self.unpack_gaussians(packed)
+                    out = render_batch(g, K[s:e].unsqueeze(0), E[s:e].unsqueeze(0), self.cfg, bg_color,
+                                       workspace=workspaces[ci], check_overflow=check_overflow, out_rgba=rgba[s:e],
+                                       return_workspace=True, camera=camera[:3])
+                    workspaces[ci] = out[1]
+        finally:  # also on _WindowTooSmall from a later frame group: the side streams' work is joined before a re-render
+            for st in used:
+                if st is not cur:
+                    cur.wait_stream(st)
         return rgba, packed_all
 
     @staticmethod
@@ -318,9 +323,15 @@ class Renderer(nn.Module):
             raise AmavError("Renderer.forward: no SMPL-X parameters (predict_smplx_params is off and no smpl_params_gt)")
 
         chunks = int(getattr(self.cfg, "pipeline_chunks", 1)) if B * T >= 32 else 1
-        self._window_bounds = None
+        window_plan = None
         if getattr(self.cfg, "upsample_triplane", False):  # renderer.py:94-99 (library convolutions, 8(f) row 2)
             up, R = self.triplane_upsampler, self.cfg.triplane_resolution
+            if up.training:
+                # crops, tile mosaics (with zero filler cells) and the < 2 GiB batch chunks all change what a
+                # training-mode BatchNorm2d would average over (and would overwrite its running statistics with it); the
+                # point refiner folds its BatchNorms as eval too.  This package is inference-only.
+                raise AmavError("Renderer.forward: the triplane upsampler is in training mode; its BatchNorm layers are "
+                                "evaluated with running statistics only -- call .eval() on the module first")
             coarse = tokens
             if getattr(self.cfg, "upsample_windows", True):
                 # only the texels the body's points can sample are upsampled (TriplaneUpsampler, "windowed evaluation")
@@ -328,13 +339,13 @@ class Renderer(nn.Module):
                 margin = float(getattr(self.cfg, "upsample_window_margin", 0.05)) if refiner else 0.0
                 plan = up.plan_windows(self.get_smpl_vertices(smpl_params), R, self.cfg.radius, margin)
                 tokens = up.forward_tokens_windowed(coarse, R, plan)
-                self._window_bounds = plan if refiner else None  # refined points are checked against it
+                window_plan = plan if refiner else None  # refined points are checked against it
+                self.last_window_plan = plan  # diagnostic only (tests / tools read it); never consumed by the path
             else:
                 tokens = up.forward_tokens(coarse, R)
         try:
-            rgba, packed = self.render_tokens(tokens, smpl_params, cam_params, chunks=chunks)
+            rgba, packed = self.render_tokens(tokens, smpl_params, cam_params, chunks=chunks, window_plan=window_plan)
         except _WindowTooSmall:  # the refiner moved a point past the margin: full planes, once
-            self._window_bounds = None
             tokens = self.triplane_upsampler.forward_tokens(coarse, self.cfg.triplane_resolution)
             rgba, packed = self.render_tokens(tokens, smpl_params, cam_params, chunks=chunks)
         gaussians = self.unpack_gaussians(packed)

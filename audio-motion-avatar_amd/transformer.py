@@ -41,10 +41,15 @@ SPLIT_GEMM_MAX_K = 1024    # bf16 x 3 format only: the 2048 -> 512 feed-forward 
 FP16_TARGET = 32768.0      # a tensor's bound is scaled to at most this (fp16 max 65504: 2x margin for rounding)
 
 
+_version_of = ops.tensor_version
+
+
 def _memo(name, tensors, make):
     """make() cached until one of `tensors` is modified in place, reallocated or freed."""
     key = (name,) + tuple(id(t) for t in tensors)
-    version = tuple((t._version, t.data_ptr()) for t in tensors)
+    # inference tensors (anything created under torch.inference_mode(), e.g. the fused q/k/v weight on a first forward
+    # inside it) carry no version counter and cannot be modified in place outside inference mode: identity + storage
+    version = tuple((_version_of(t), t.data_ptr()) for t in tensors)
     hit = _MEMO.get(key)
     if hit is None or hit[0] != version or any(ref() is not t for ref, t in zip(hit[1], tensors)):
         if hit is None or any(ref() is not t for ref, t in zip(hit[1], tensors)):
@@ -140,7 +145,7 @@ class Attention(nn.Module):
 
     def _qkv_weight(self):
         ws = (self.to_q.weight, self.to_k.weight, self.to_v.weight)
-        version = tuple((w._version, w.data_ptr()) for w in ws)
+        version = tuple((_version_of(w), w.data_ptr()) for w in ws)
         if self._qkv is None or self._qkv[0] != version:
             self._qkv = (version, torch.cat([w.detach() for w in ws], dim=0).contiguous())
         return self._qkv[1]
@@ -340,7 +345,7 @@ class Transformer1D_nn(nn.Module):
         of two tiny GEMVs inside every block.  -> [L,B,1,dim]"""
         mods = [b.attn2 for b in self.transformer_blocks]
         tensors = [t for m in mods for t in (m.to_v.weight, m.to_out[0].weight, m.to_out[0].bias)]
-        version = tuple((t._version, t.data_ptr()) for t in tensors)
+        version = tuple((_version_of(t), t.data_ptr()) for t in tensors)
         if self._cross is None or self._cross[0] != version:
             wv = torch.stack([m.to_v.weight.detach().t() for m in mods]).contiguous()        # [L,ctx,inner]
             wo = torch.stack([m.to_out[0].weight.detach().t() for m in mods]).contiguous()   # [L,inner,dim]

@@ -39,7 +39,9 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-PROFILE_TAG = "r02"  # the committed rocprofv3 summaries of THIS build (tools/gpu_profiles.sh + collect_profiles.py)
+PROFILE_TAG = "r03"  # the committed rocprofv3 summaries of THIS build (tools/gpu_profiles.sh + collect_profiles.py)
+# objects measured after the timed region of the default line; each may carry a `parity` with an explicit `pass`
+EXTRA_OBJECTS = ("full_path", "full_path_exact_fp32", "point_refiner", "reference_defaults", "stress")
 
 
 def _profile_row(filename, kernel_substr):
@@ -311,6 +313,12 @@ class FullPath:
                   "smpl_tokens_max_abs": float((got_smpl.cpu() - ref_smpl).abs().max()),
                   "token_tolerance": 2e-5 * max(1.0, scale),
                   "rgb": pixel_report(d_rgb.amax(-1), unstable[0]), "raster_tolerance": 1e-3}
+        # tokens within the stated tolerance; no unflagged pixel above 1e-3 and no more pixels above it than the oracle
+        # flagged as sitting on a blend threshold (the rule of the render workload's `parity`)
+        parity["pass"] = bool(max(parity["triplane_tokens_max_abs"], parity["smpl_tokens_max_abs"]) <= parity["token_tolerance"]
+                              and parity["rgb"]["unflagged_pixels_above_tolerance"] == 0
+                              and parity["rgb"]["pixels_above_tolerance"] <= parity["rgb"]["pixels_flagged"]
+                              and parity["rgb"]["max_abs_all_pixels"] <= 1.2e-2)
         base = {"value": 1.0 / (ar_sec + render_sec), "unit": "frames/s", "cores": cores, "kind": "port",
                 "sample": f"{ar_steps} autoregressive steps of the full-size net (8 layers, S=6304) + their {ar_steps} "
                           f"rendered 512x512 frames through oracle/ (torch CPU, {cores} threads; C rasterizer with OpenMP): "
@@ -615,7 +623,8 @@ def cpu_baseline_and_parity(renderer, cfg, tokens, smpl, cam, step_outputs, n_fr
     }
     parity["pass"] = bool(parity["lbs_points_max_abs"] <= 1e-5 and parity["decode_max_abs"] <= 2e-5 and
                           all(r["unflagged_pixels_above_tolerance"] == 0 and
-                              r["pixels_above_tolerance"] <= r["pixels_flagged"] for r in (rgb_report, alpha_report)))
+                              r["pixels_above_tolerance"] <= r["pixels_flagged"] and
+                              r["max_abs_all_pixels"] <= 1.2e-2 for r in (rgb_report, alpha_report)))
     base = {"value": n_frames / sec, "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"{n_frames} frames of the same workload through oracle/ (torch CPU LBS + grid_sample/linear "
                       f"decode with {cores} threads, C rasterizer with OpenMP), median of 3 after 1 warm-up"}
@@ -823,8 +832,9 @@ def main():
         emit(result)
     if dist is not None:
         dist.destroy_process_group()
-    failed = [k for k in ("parity",) if not result.get(k, {}).get("pass", True)]
-    failed += [k for k in ("full_path", "point_refiner") if not result.get(k, {}).get("parity", {}).get("pass", True)]
+    # a parity object that exists must carry an explicit `pass`: a missing flag is a failure, not a success
+    failed = [k for k in ("parity",) if k in result and result[k].get("pass") is not True]
+    failed += [k for k in EXTRA_OBJECTS if "parity" in result.get(k, {}) and result[k]["parity"].get("pass") is not True]
     if rank == 0 and failed:
         raise SystemExit(f"parity check against the CPU oracle FAILED in {failed} (see the JSON line)")
 

@@ -294,7 +294,7 @@ def test_windowed_upsampler_with_refiner_and_fallback():
             _, g_full = r_full(tokens, cam, dummy, smpl)
         assert bool(calls) == expect_fallback, (shift, calls)
         if not expect_fallback:
-            plan = r_win._window_bounds
+            plan = r_win.last_window_plan
             assert all(w["tiles"] is not None and 0 < len(w["tiles"]) <= 32 * F_ for w in plan)  # really tiled: <= half
         for k in ("xyz", "scale", "rot", "opacity", "color"):
             assert (g_win[k] - g_full[k]).abs().max() <= 2e-5, (shift, k)

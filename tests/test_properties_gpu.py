@@ -283,3 +283,84 @@ def test_render_step_is_hip_graph_capturable(full_clip):
             graph.replay()
         torch.cuda.synchronize()
         assert torch.equal(out, want)
+
+
+def _capture(fn):
+    """fn() captured into a HIP graph on a side stream (kernel nodes only: the library clears with zero_async)."""
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            out = fn()
+    torch.cuda.current_stream().wait_stream(side)
+    return graph, out
+
+
+def test_measured_bounds_attention_is_hip_graph_capturable():
+    """VERDICT r2 item 2 / ADVICE: amav_selfattn_forward without proven bounds clears its 16-byte magnitude header
+    before the absmax pre-pass.  That clear was a hipMemsetAsync -- the ingredient of round 1's replay fault (memset node
+    of a linear graph + an eager memset of the same entry point between two replays).  It is a zero-fill kernel now: the
+    measured-bounds call captures, replays bit-identically, follows in-place input changes, with eager calls of the
+    same entry point between replays.  Run once per change (a fault here is diagnosed, not retried)."""
+    from audio_motion_avatar_amd import ops
+
+    g = torch.Generator().manual_seed(3)
+    B, S, H, D = 1, 700, 2, 64
+    qkv = torch.randn(B, S, 3 * H * D, generator=g).cuda()
+    i = H * D
+    call = lambda: ops.selfattn(qkv[..., :i], qkv[..., i:2 * i], qkv[..., 2 * i:], H)  # bounds=None: measured
+    with torch.no_grad():
+        eager = call().clone()
+        torch.cuda.synchronize()
+        graph, out = _capture(call)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, eager)
+        qkv.mul_(3.0)                      # new magnitudes: the replayed absmax pass must see them
+        want = call().clone()              # eager call of the same entry point between two replays
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, want) and not torch.equal(want, eager)
+        for _ in range(3):
+            call()
+            graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, want)
+    ref = torch.nn.functional.scaled_dot_product_attention(
+        *(t.view(B, S, H, D).transpose(1, 2).double() for t in (qkv[..., :i], qkv[..., i:2 * i], qkv[..., 2 * i:])))
+    assert float((out.view(B, S, H, D).transpose(1, 2).double() - ref).abs().max()) <= 2e-5
+
+
+def test_refiner_convolution_is_hip_graph_capturable():
+    """Same property for amav_subm_pair_gemm_split (every point-refiner convolution): its scratch clear is a kernel."""
+    import numpy as np
+
+    from audio_motion_avatar_amd import ops, point_transformer as pt
+
+    g = torch.Generator().manual_seed(5)
+    F_, N, cin, cout = 2, 600, 64, 64
+    d = torch.nn.functional.normalize(torch.randn(F_, N, 3, generator=g), dim=-1) * torch.tensor([0.3, 0.5, 0.2])
+    n = F_ * N
+    cloud_of = torch.arange(F_, dtype=torch.int32).repeat_interleave(N).cuda()
+    grid, depth = ops.cloud_voxelize(d.reshape(n, 3).cuda(), cloud_of, F_)
+    level = pt.Level(grid, cloud_of, depth, np.full(F_, N), ops.cloud_codes(grid, cloud_of, depth))
+    conv = pt.SubMConv3d(cin, cout, 3, bias=True).cuda()
+    feat = torch.randn(n, cin, generator=g).cuda()
+    with torch.no_grad():
+        eager = conv(feat, level).clone()   # builds the pair tables and the split weights (host syncs: outside capture)
+        torch.cuda.synchronize()
+        graph, out = _capture(lambda: conv(feat, level))
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, eager)
+        feat.mul_(40.0)
+        want = conv(feat, level).clone()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, want) and not torch.equal(want, eager)
+        for _ in range(3):
+            conv(feat, level)
+            graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, want)

@@ -42,7 +42,7 @@ for label, kw in (("upsampler + refiner, 30k", dict(upsample_triplane=True, no_p
             images, _ = r(tokens, cam, dummy, smpl)
         torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 3 / F
-    plan = getattr(r, "_window_bounds", None)
+    plan = getattr(r, "last_window_plan", None)
     tiles = [round(int(w["mask"].sum()) / F, 1) for w in plan] if plan else None
     print(f"{label:28s} {dt * 1e3:8.2f} ms per frame ({F} frames per call), coverage {float((images < 0.999).any(-1).float().mean()):.3f}"
           f", active tiles of 64 per plane {tiles}", flush=True)
