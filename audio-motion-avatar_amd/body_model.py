@@ -320,8 +320,6 @@ class BodyModel(torch.nn.Module):
             # per device placement of the table
             key = (self._blend.data_ptr(), ops.tensor_version(self._blend))
             if getattr(self, "_blend_split", None) is None or self._blend_split[0] != key:
-                from . import ops
-
                 self._blend_split = (key, ops.lbs_prepare_blend_split(tables))
             tables["blend_split"] = self._blend_split[1]
         return tables

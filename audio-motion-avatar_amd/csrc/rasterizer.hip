@@ -27,6 +27,7 @@
 //                  queues (one per XCD: tile-row bands, rotating with the frame) bucketed by list length and
 //                  dispatched longest first.
 #include <algorithm>
+#include <cstddef>
 #include <cstdlib>
 
 #include "amav_common.h"
@@ -65,7 +66,7 @@ struct Status {
 };
 
 struct Buffers {
-    float4 *geom;              // [F*N][3]: {x, y, conA', conB'} {conC', opacity, r, g} {b, 1/depth, hx, hy}
+    float4 *geom;              // [F*N][3]: {x, y, qa, qb} {qc, log2(opacity), r, g} {b, 1/depth, hx, hy} (preprocess_one)
     uint4 *rectd;              // [F*N]: {rx0 | ry0 << 16, rx1 | ry1 << 16, depth bits, radius}
     int *tile_off;             // [F*(T+1)] exclusive scan within the frame
     unsigned long long *keys;  // [F * cap_per_frame]
@@ -229,7 +230,10 @@ __device__ __forceinline__ uint4 preprocess_one(const Params &p, int f, int i, c
     const float det = ca * cc - cb * cb;
     float h_scale = 1.0f;
     if (p.antialiasing) h_scale = sqrtf(fmaxf(0.000025f, det_cov / det));
-    if (det == 0.0f) return rd;
+    // upstream skips det == 0.  det < 0 cannot happen for a real covariance (J W Sigma W^T J^T is positive
+    // semi-definite and 0.3 is added to its diagonal); a record that gets there by overflow / NaN inputs is dropped too
+    // (upstream would blend an indefinite form), which is what lets the blend kernel use the square-root form below.
+    if (!(det > 0.0f)) return rd;
     const float det_inv = 1.0f / det;
     const float mid = 0.5f * (ca + cc);
     const float root = sqrtf(fmaxf(0.1f, mid * mid - det));
@@ -266,10 +270,18 @@ __device__ __forceinline__ uint4 preprocess_one(const Params &p, int f, int i, c
     rd = make_uint4((unsigned)cx0 | ((unsigned)cy0 << 16), (unsigned)cx1 | ((unsigned)cy1 << 16), __float_as_uint(vz),
                     (unsigned)(int)my_radius);
     float4 *g = p.buf.geom + gi * 3;
-    // the conic is stored as the coefficients of log2(alpha / op) = A' dx^2 + B' dx dy + C' dy^2, i.e. pre-multiplied
-    // by log2(e) and by the -1/2 and -1 of the exponent (both exact): the blend is two multiplies, an add, an fma, exp2
-    g[0] = make_float4(pix_x, pix_y, -0.5f * ((cc * det_inv) * kLog2e), (cb * det_inv) * kLog2e);
-    g[1] = make_float4(-0.5f * ((ca * det_inv) * kLog2e), op, c0, c1);
+    // The blend needs log2(alpha) = log2(op) + log2(e) * power, power = -1/2 (A dx^2 + C dy^2) - B dx dy with the conic
+    // (A, B, C) = (cc, -cb, ca) / det.  The quadratic form is stored as its Cholesky factor: with k = log2(e) / 2,
+    //     -log2(e) * power = (a dx + b dy)^2 + (c dy)^2,   a = sqrt(k A), b = k B / a, c = sqrt(k (C - B^2 / A)) = sqrt(k / cc)
+    // (A C - B^2 = 1 / det).  A sum of squares is >= 0 in floating point too, so upstream's "power > 0 -> skip" guard
+    // (which only ever fires on rounding noise of ITS three-term form) has nothing left to catch, and the blend kernel
+    // evaluates log2(alpha) in five fused multiply-adds (blend_px).
+    const float kk = 0.5f * kLog2e;
+    const float qa = sqrtf(kk * (cc * det_inv));
+    const float qb = -(kk * (cb * det_inv)) / qa;
+    const float qc = sqrtf(kk / cc);
+    g[0] = make_float4(pix_x, pix_y, qa, qb);
+    g[1] = make_float4(qc, log2f(op), c0, c1);
     g[2] = make_float4(c2, 1.0f / vz, bx, by);
     return rd;
 }
@@ -588,10 +600,25 @@ __global__ __launch_bounds__(256) void sort_big_kernel(Params p) {
 // --------------------------------------------------------------------------------------------------------- render
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+constexpr int kNullSlot = 64;  // staging slot of the null record (log2(opacity) = -inf): what list padding points at
+
 struct WaveLds {
-    unsigned long long keys[kSortCap];  // keys, then (in place) the blend order as 32-bit Gaussian ids
-    float4 stage[3][65];                // staged records {x, y, A', B'} {C', opacity, r, g} {b, 1/depth, ..}; [64] = null record
+    // keys of the tile's list while it is sorted, then (in place) the blend order as 32-bit Gaussian ids in the first
+    // 2 KiB and, behind them, the four quadrant lists of the current staging round
+    unsigned long long keys[kSortCap];
+    // staged records, [64] = null record.  Three planes at fixed distances (immediate offsets of the blend loop's reads):
+    float4 geo[65];   // +0     {k0, k1, qa, qb}
+    float4 col[65];   // +1040  {r, g, b, 1/depth}
+    float4 geo2[65];  // +2080  {qc, log2(opacity), -, -}: 16-byte slots like the other planes (one slot address serves all three)
 };
+static_assert(offsetof(WaveLds, col) - offsetof(WaveLds, geo) == 1040 && offsetof(WaveLds, geo2) - offsetof(WaveLds, geo) == 2080,
+              "blend_quadrant's ds_read offsets");
+// quadrant lists: LDS byte addresses of the staged records that reach the quadrant, in blend order; blend_quadrant walks
+// them two entries at a time and reads up to two pairs past the end, so the tail is padded with the null record's address
+constexpr int kListStride = 72;
+constexpr int kListTail = 5;  // pad entries behind the last real one: up to entry 2 * ceil(n / 2) + 3
+static_assert(64 + kListTail <= kListStride && kListStride % 2 == 0, "list padding");
+static_assert(kSortCap * 4 + 4 * kListStride * 4 <= kSortCap * 8, "quadrant lists must fit behind the id list");
 
 // Rank sort of n <= 64 * KPL unique keys held in LDS: rank = number of smaller keys, no cross-lane exchange.  The
 // 32-bit ids then overwrite the key slice in blend order (every lane has read all keys by then).
@@ -633,7 +660,7 @@ constexpr int kBuckets512 = 512;
 constexpr int kBucketMax = 16;
 
 template <int KPL>
-__device__ __forceinline__ bool bucket_sort(const unsigned long long *__restrict__ gkeys, unsigned long long *slice,
+__device__ __attribute__((noinline)) bool bucket_sort(const unsigned long long *__restrict__ gkeys, unsigned long long *slice,
                                             unsigned *cnt, unsigned *order, int n, int lane) {
     unsigned long long k[KPL];
     unsigned dmin = 0xffffffffu, dmax = 0u;
@@ -730,7 +757,7 @@ __device__ __forceinline__ bool bucket_sort(const unsigned long long *__restrict
 // against the rank sort's O(n^2 / 64) compares; it wins above 256 keys (measured: 31 us against 52 us per tile for
 // n in [256, 512), 16 against 13 for [128, 256)).  Normalised network (every comparator orders lo < hi ascending), so
 // the "+inf" tail up to the next power of two needs no storage: comparators that reach past n are skipped.
-__device__ __forceinline__ void wave_bitonic_sort(unsigned long long *a, unsigned *order, int n, int lane) {
+__device__ __attribute__((noinline)) void wave_bitonic_sort(unsigned long long *a, unsigned *order, int n, int lane) {
     const int lp = 32 - __builtin_clz(n - 1);  // P = 2^lp >= n
     const int half = 1 << (lp - 1);
     auto cmpswap = [&](int lo, int hi) {
@@ -769,97 +796,119 @@ __device__ __forceinline__ void wave_bitonic_sort(unsigned long long *a, unsigne
     wave_sync();
 }
 
-// One pixel, one Gaussian.  T > 0: live transmittance; T < 0: pixel finished, |T| is its final transmittance.
-// A finished pixel needs no test of its own: with T < 0 the weight alpha*T is negative, T - alpha*T < 1e-4 holds, so
-// the Gaussian is either invalid (w = 0) or takes the "finished" branch (w = 0, T <- -|T| = T).
-// Record words: a = {x, y, A', B'}, b = {C', opacity, r, g}, c = {b, 1/depth}; A' B' C' are the coefficients of
-// log2(alpha / opacity) = A' dx^2 + B' dx dy + C' dy^2 (bin_kernel), evaluated as dx (A' dx + B' dy) + (C' dy) dy.
+// ---- the blend loop
+// One pixel (lane), one Gaussian.  T > 0: live transmittance; T < 0: pixel finished, |T| is its final transmittance.
+// Staged record: geo = {k0, k1, qa, qb}, geo2 = {qc, L = log2(opacity)}, col = {r, g, b, 1/depth}; (lx, ly) = the pixel
+// relative to the tile origin.  log2(alpha) = L - u^2 - v^2 with u = qa dx + qb dy = k0 - qa lx - qb ly and
+// v = qc dy = k1 - qc ly (preprocess_one; k0, k1 are formed per tile when the record is staged): five fused
+// multiply-adds, and never above L, so upstream's "power > 0" skip has no case left.  Then, as upstream:
+//     alpha = min(0.99, 2^..);  alpha < 1/255 -> skip;  T' = T (1 - alpha);  T' < 1e-4 -> pixel finished (not blended)
+//     C += colour * alpha * T;  T = T'
+// A finished pixel needs no test of its own: with T < 0, T - alpha T < 1e-4 holds, the Gaussian takes the "finished"
+// branch (weight 0, T <- -|T| = T).  17 vector instructions per pixel and Gaussian (18 with inverse depth).
+//
+// The loop is written in assembly (one statement, guide section 5.7 form (i): its LDS reads and their waits are all
+// inside).  Compiled from C++ the same loop came out at 27 vector + 15 scalar instructions per Gaussian in round 2 (mask
+// walking, register copies at the back edge, lgkmcnt(0) before every group) and, rewritten over address lists, lost its
+// software pipeline to the scheduler (every record read hoisted to the loop top and waited for at once).
+//
+// Registers: v68..v95 are named literally and listed as clobbers (two record sets of ten, two pairs of list entries,
+// three temporaries); the state (T, R, G, B, D) and inputs are ordinary operands.
+// Pipeline (LDS returns in order, so every wait is a count): iteration k blends pair k = records A, B while it
+//   * reads the list entries of pair k+2 (top of the iteration),
+//   * re-reads each record's registers for pair k+1 as soon as the last instruction using them has issued: the six
+//     geometry words after the fourth multiply-add, the colour words after the colour multiply-adds,
+// so a read is issued about one Gaussian (~20 instructions of this wave, times the waves sharing the SIMD) before its
+// use.  At the top of an iteration the queue holds [entries(k+1)] A.geo A.geo2 A.col B.geo B.geo2 B.col + the new
+// entries(k+2) = 8 reads; the waits below are lgkmcnt(5) before each record's geometry and lgkmcnt(6) before its colours.
+// Software-managed hazards of gfx950 respected inside the string: a VALU write of VCC needs two instructions before
+// the VALU that reads it as a mask; a transcendental's result one before its VALU consumer.
+#define AMAV_BLEND_GEO(k0, k1, qa, qb, qc, L) /* u -> v92 = L - u^2 (v^2 still to subtract), v -> v93 */          \
+    "v_fma_f32 v92, -" qb ", %[ly], " k0 "\n\t"                                                                    \
+    "v_fma_f32 v93, -" qc ", %[ly], " k1 "\n\t"                                                                    \
+    "v_fma_f32 v92, -" qa ", %[lx], v92\n\t"                                                                       \
+    "v_fma_f32 v92, -v92, v92, " L "\n\t"
+#define AMAV_BLEND_REST(r, g, b, d, col_wait, DEPTH)                                                               \
+    "v_fma_f32 v92, -v93, v93, v92\n\t"                                                                            \
+    "v_exp_f32_e32 v92, v92\n\t"                                                                                   \
+    "s_nop 0\n\t"                                                                                                  \
+    "v_min_f32_e32 v92, 0x3f7d70a4, v92\n\t"            /* min(0.99, .) */                                        \
+    "v_cmp_le_f32_e32 vcc, 0x3b808081, v92\n\t"         /* 1/255 <= alpha */                                      \
+    "s_nop 1\n\t"                                                                                                  \
+    "v_cndmask_b32_e32 v92, 0, v92, vcc\n\t"            /* else alpha = 0 (also NaN) */                           \
+    "v_fma_f32 v93, -v92, %[T], %[T]\n\t"               /* T' = T - alpha T */                                    \
+    "v_cmp_gt_f32_e32 vcc, 0x38d1b717, v93\n\t"         /* T' < 1e-4: finished */                                 \
+    "v_mul_f32_e32 v94, v92, %[T]\n\t"                  /* weight alpha T */                                      \
+    "s_nop 0\n\t"                                                                                                  \
+    "v_cndmask_b32_e64 v94, v94, 0, vcc\n\t"                                                                       \
+    "v_cndmask_b32_e64 %[T], v93, -|%[T]|, vcc\n\t"                                                                \
+    col_wait                                                                                                       \
+    "v_fmac_f32_e32 %[R], " r ", v94\n\t"                                                                          \
+    "v_fmac_f32_e32 %[G], " g ", v94\n\t"                                                                          \
+    "v_fmac_f32_e32 %[B], " b ", v94\n\t" DEPTH(d)
+#define AMAV_DEPTH_ON(d) "v_fmac_f32_e32 %[D], " d ", v94\n\t"
+#define AMAV_DEPTH_OFF(d)
+// one pair: records A = v[68:77] (geo 68..71, geo2 72..73, col 74..77), B = v[78:87]; `use` = the register pair holding
+// the entries of the next pair (addresses of its records), `load` = the pair that receives the entries after that
+#define AMAV_BLEND_PAIR(use_x, use_y, load, DEPTH)                                                                 \
+    "ds_read_b64 " load ", %[list] offset:16\n\t"                                                                  \
+    "v_add_u32_e32 %[list], 8, %[list]\n\t"                                                                        \
+    "s_waitcnt lgkmcnt(5)\n\t"                                                                                     \
+    AMAV_BLEND_GEO("v68", "v69", "v70", "v71", "v72", "v73")                                                       \
+    "ds_read_b128 v[68:71], " use_x "\n\t"                                                                         \
+    "ds_read_b64 v[72:73], " use_x " offset:2080\n\t"                                                              \
+    AMAV_BLEND_REST("v74", "v75", "v76", "v77", "s_waitcnt lgkmcnt(6)\n\t", DEPTH)                                 \
+    "ds_read_b128 v[74:77], " use_x " offset:1040\n\t"                                                             \
+    "s_waitcnt lgkmcnt(5)\n\t"                                                                                     \
+    AMAV_BLEND_GEO("v78", "v79", "v80", "v81", "v82", "v83")                                                       \
+    "ds_read_b128 v[78:81], " use_y "\n\t"                                                                         \
+    "ds_read_b64 v[82:83], " use_y " offset:2080\n\t"                                                              \
+    AMAV_BLEND_REST("v84", "v85", "v86", "v87", "s_waitcnt lgkmcnt(6)\n\t", DEPTH)                                 \
+    "ds_read_b128 v[84:87], " use_y " offset:1040\n\t"
+#define AMAV_BLEND_LOOP(DEPTH)                                                                                     \
+    "s_waitcnt lgkmcnt(0)\n\t"                          /* nothing of the compiler's may be in flight: counted waits */ \
+    "ds_read_b64 v[88:89], %[list]\n\t"                                                                            \
+    "ds_read_b64 v[90:91], %[list] offset:8\n\t"                                                                   \
+    "s_waitcnt lgkmcnt(1)\n\t"                                                                                     \
+    "ds_read_b128 v[68:71], v88\n\t"                                                                               \
+    "ds_read_b64 v[72:73], v88 offset:2080\n\t"                                                                    \
+    "ds_read_b128 v[74:77], v88 offset:1040\n\t"                                                                   \
+    "ds_read_b128 v[78:81], v89\n\t"                                                                               \
+    "ds_read_b64 v[82:83], v89 offset:2080\n\t"                                                                    \
+    "ds_read_b128 v[84:87], v89 offset:1040\n\t"                                                                   \
+    "1:\n\t"                                                                                                       \
+    AMAV_BLEND_PAIR("v90", "v91", "v[88:89]", DEPTH)                                                               \
+    "s_sub_u32 %[groups], %[groups], 1\n\t"                                                                        \
+    "s_cmp_eq_u32 %[groups], 0\n\t"                                                                                \
+    "s_cbranch_scc1 2f\n\t"                                                                                        \
+    AMAV_BLEND_PAIR("v88", "v89", "v[90:91]", DEPTH)                                                               \
+    "v_cmp_lt_f32_e32 vcc, 0, %[T]\n\t"                 /* some pixel of the quadrant still takes Gaussians */    \
+    "s_sub_u32 %[groups], %[groups], 1\n\t"                                                                        \
+    "s_cmp_eq_u32 %[groups], 0\n\t"                                                                                \
+    "s_cbranch_scc1 2f\n\t"                                                                                        \
+    "s_cbranch_vccnz 1b\n\t"                                                                                       \
+    "2:\n\t"                                                                                                       \
+    "s_waitcnt lgkmcnt(0)\n\t"                          /* the reads issued ahead land before the registers are reused */
+#define AMAV_BLEND_CLOBBERS                                                                                        \
+    "memory", "vcc", "scc", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79",    \
+        "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94"
+
+// One 8x8 quadrant of the tile (one pixel per lane) against the staged Gaussians of its list: `list` = LDS byte address
+// of the list, `groups` = ceil(entries / 2) >= 1.  Returns false when every pixel of the quadrant has finished.
 template <bool kInvDepth>
-__device__ __forceinline__ void blend_px(const float4 &a, const float4 &b, const float2 &c, float px, float py,
-                                         float &T, float &Cr, float &Cg, float &Cb, float &Dp) {
-    const float dx = a.x - px, dy = a.y - py;
-    const float power2 = fmaf(dx, fmaf(a.w, dy, a.z * dx), (b.x * dy) * dy);
-#if AMAV_ABLATE == 2  /* diagnostic build: no transcendental */
-    float alpha = fminf(0.99f, b.y * (power2 + 1.0f));
-#else
-    float alpha = fminf(0.99f, b.y * __builtin_amdgcn_exp2f(power2));
-#endif
-    // The three decisions of the reference (skip power > 0, skip alpha < 1/255, stop at T' < 1e-4) as compare + select
-    // pairs on VCC only: no SGPR-pair logic between vector instructions (each v_cmp -> s_and -> v_cndmask round trip
-    // parks the wave until the vector pipe has drained).
-    alpha = power2 <= 0.0f ? alpha : 0.0f;
-    alpha = alpha >= (1.0f / 255.0f) ? alpha : 0.0f;  // 0: this Gaussian does not touch the pixel
-    const float w0 = alpha * T;
-    const float test_T = T - w0;       // = T (1 - alpha) up to one rounding; = T when alpha was zeroed
-    // A live pixel has T >= 1e-4 (it would have finished otherwise), so with alpha = 0 the test below is false; a
-    // finished pixel (T < 0) gives test_T < 0 and re-takes the "finished" branch, which leaves it as it is.
-    const bool fin = test_T < 0.0001f;
-    const float w = fin ? 0.0f : w0;
-    Cr = fmaf(b.z, w, Cr);
-    Cg = fmaf(b.w, w, Cg);
-    Cb = fmaf(c.x, w, Cb);
-    if (kInvDepth) Dp = fmaf(c.y, w, Dp);
-    T -= w;                    // unchanged unless this Gaussian was blended
-    T = fin ? -fabsf(T) : T;   // finished: the saturating Gaussian is not blended, the sign marks the pixel done
-}
-
-struct StageRec {
-    float4 a, b;
-    float2 c;
-};
-
-__device__ __forceinline__ StageRec read_stage(const WaveLds &L, int j) {  // j is wave-uniform: broadcast reads
-    StageRec r;
-    r.a = L.stage[0][j];
-    r.b = L.stage[1][j];
-    r.c = *reinterpret_cast<const float2 *>(&L.stage[2][j]);
-    return r;
-}
-
-constexpr int kNullSlot = 64;  // staging slot of a record with opacity 0: what an exhausted list keeps reading
-
-// Next set bit of a wave-uniform mask, cleared, in three scalar instructions; an exhausted mask yields kNullSlot, so
-// the caller's LDS reads stay unconditional and the compiler can count them exactly in its s_waitcnt (a read under a
-// branch makes every later wait assume the worst: "everything issued so far").
-__device__ __forceinline__ int next_bit(unsigned long long &mask) {
-    int j;
-    asm("s_ff1_i32_b64 %0, %1\n\ts_bitset0_b64 %1, %0\n\ts_min_u32 %0, %0, %2" : "=&s"(j), "+s"(mask) : "n"(kNullSlot) : "scc");
-    return j;  // s_ff1 of 0 is -1: bit 63 of the (empty) mask is "cleared" and the unsigned minimum gives 64
-}
-
-// One 8x8 quadrant of the tile (one pixel per lane) against the staged Gaussians whose bit is set in `mask` (a
-// wave-uniform 64-bit ballot, i.e. scalar registers: the loop walks its set bits with scalar instructions, lowest =
-// nearest first, so the blend order is the staged order).  Records are read from LDS two Gaussians ahead of their use
-// (three register sets, loop unrolled by three); the list is processed in threes, the last
-// group padded with the null record, so there is one loop branch per three Gaussians.  Returns false when every
-// pixel of the quadrant has finished (checked every six Gaussians).
-template <bool kInvDepth>
-__device__ __forceinline__ bool blend_quadrant(unsigned long long mask, const WaveLds &L, float px, float py, float &T,
-                                               float &R, float &G, float &B, float &D) {
-    int groups = (__popcll(mask) + 2) / 3;  // >= 1
-    StageRec r0 = read_stage(L, next_bit(mask));
-    StageRec r1 = read_stage(L, next_bit(mask)), r2;
-    bool alive = true;  // wave-uniform: some pixel of the quadrant still takes Gaussians
-    do {  // one back edge, one exit (two exits cost five scalar branches per group instead of two; same speed)
-#if AMAV_ABLATE == 1  /* diagnostic build: no LDS reads inside the loop */
-        (void)next_bit(mask); (void)next_bit(mask); (void)next_bit(mask);
-        r2 = r0;
-        asm volatile("" : "+v"(r0.a.x), "+v"(r1.a.x), "+v"(r2.a.x));
-        blend_px<kInvDepth>(r0.a, r0.b, r0.c, px, py, T, R, G, B, D);
-        blend_px<kInvDepth>(r1.a, r1.b, r1.c, px, py, T, R, G, B, D);
-        blend_px<kInvDepth>(r2.a, r2.b, r2.c, px, py, T, R, G, B, D);
-#else
-        r2 = read_stage(L, next_bit(mask));
-        blend_px<kInvDepth>(r0.a, r0.b, r0.c, px, py, T, R, G, B, D);
-        r0 = read_stage(L, next_bit(mask));
-        blend_px<kInvDepth>(r1.a, r1.b, r1.c, px, py, T, R, G, B, D);
-        r1 = read_stage(L, next_bit(mask));
-        blend_px<kInvDepth>(r2.a, r2.b, r2.c, px, py, T, R, G, B, D);
-#endif
-        --groups;
-        if ((groups & 1) == 0) alive = __any(T > 0.f);  // a finished quadrant takes no further Gaussians (every six)
-    } while (groups != 0 && alive);
-    return alive && __any(T > 0.f);
+__device__ __forceinline__ bool blend_quadrant(unsigned list, int groups, float lx, float ly, float &T, float &R,
+                                               float &G, float &B, float &D) {
+    if (kInvDepth)
+        asm volatile(AMAV_BLEND_LOOP(AMAV_DEPTH_ON)
+                     : [T] "+v"(T), [R] "+v"(R), [G] "+v"(G), [B] "+v"(B), [D] "+v"(D), [list] "+v"(list), [groups] "+s"(groups)
+                     : [lx] "v"(lx), [ly] "v"(ly)
+                     : AMAV_BLEND_CLOBBERS);
+    else
+        asm volatile(AMAV_BLEND_LOOP(AMAV_DEPTH_OFF)
+                     : [T] "+v"(T), [R] "+v"(R), [G] "+v"(G), [B] "+v"(B), [list] "+v"(list), [groups] "+s"(groups)
+                     : [lx] "v"(lx), [ly] "v"(ly)
+                     : AMAV_BLEND_CLOBBERS);
+    return __any(T > 0.f);
 }
 
 #define AMAV_STAMP(slot)                                                                              \
@@ -900,9 +949,9 @@ __device__ __forceinline__ void render_tile(const Params &p, WaveLds &L, int ite
     const int X0 = tx * kTile, Y0 = ty * kTile;
     // this lane's four pixels: (X0 + 8*qx + lx, Y0 + 8*qy + ly), quadrant q = qx + 2*qy
     const int lx = lane & 7, ly = lane >> 3;
-    float pxf0 = (float)(X0 + lx), pxf1 = (float)(X0 + 8 + lx);
-    float pyf0 = (float)(Y0 + ly), pyf1 = (float)(Y0 + 8 + ly);
-    asm volatile("" : "+v"(pxf0), "+v"(pxf1), "+v"(pyf0), "+v"(pyf1));  // keep them in registers (no re-convert)
+    // pixel coordinates relative to the tile origin (blend_px works in the tile's frame)
+    float lxf0 = (float)lx, lxf1 = (float)(8 + lx), lyf0 = (float)ly, lyf1 = (float)(8 + ly);
+    asm volatile("" : "+v"(lxf0), "+v"(lxf1), "+v"(lyf0), "+v"(lyf1));  // keep them in registers (no re-convert)
     const bool in0 = X0 + lx < p.W, in1 = X0 + 8 + lx < p.W, inr0 = Y0 + ly < p.H, inr1 = Y0 + 8 + ly < p.H;
 
     float T0 = (in0 & inr0) ? 1.f : -1.f, T1 = (in1 & inr0) ? 1.f : -1.f;
@@ -920,14 +969,8 @@ __device__ __forceinline__ void render_tile(const Params &p, WaveLds &L, int ite
         const unsigned *order_g = p.buf.sorted + (size_t)f * p.cap_per_frame + beg;  // long lists only
         unsigned *order_l = reinterpret_cast<unsigned *>(L.keys);
         const bool local = n <= kSortCap;
-#if AMAV_ABLATE == 4 || AMAV_ABLATE == 8
         if (local) {
-            for (int k = lane; k < n; k += 64) order_l[k] = (unsigned)keys[k];
-            wave_sync();
-        } else
-#endif
-        if (local) {
-            unsigned *cnt = reinterpret_cast<unsigned *>(L.stage);  // the staging buffers are idle while sorting
+            unsigned *cnt = reinterpret_cast<unsigned *>(L.geo);  // the staging buffers are idle while sorting
             bool done = false;
             if (n <= 64) {
                 for (int k = lane; k < n; k += 64) L.keys[k] = keys[k];
@@ -956,8 +999,12 @@ __device__ __forceinline__ void render_tile(const Params &p, WaveLds &L, int ite
             }
         }
         AMAV_STAMP(2);
-        // the sorts used the staging buffers as scratch: (re)write the null record (opacity 0 blends nothing)
-        if (lane < 3) L.stage[lane][kNullSlot] = make_float4(0.f, 0.f, 0.f, 0.f);
+        // the sorts used the staging buffers as scratch: (re)write the null record (log2(opacity) = -inf blends nothing)
+        if (lane == 0) {
+            L.geo[kNullSlot] = make_float4(0.f, 0.f, 0.f, 0.f);
+            L.col[kNullSlot] = make_float4(0.f, 0.f, 0.f, 0.f);
+            L.geo2[kNullSlot] = make_float4(0.f, -__builtin_inff(), 0.f, 0.f);
+        }
 
         // ---- blend, 64 Gaussians per staging round
         const float4 *geom = p.buf.geom + (size_t)f * p.N * 3;
@@ -978,6 +1025,10 @@ __device__ __forceinline__ void render_tile(const Params &p, WaveLds &L, int ite
         };
         if (lane < n) load_records(lane);
         const float X0f = (float)X0, Y0f = (float)Y0;
+        // LDS byte addresses (the quadrant lists hold addresses, so the blend loop does no address arithmetic)
+        const unsigned stage_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)&L.geo[0];
+        const unsigned lists_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)&L.keys[kSortCap / 2];
+        const unsigned my_slot = stage_base + (unsigned)lane * 16u, null_slot = stage_base + (unsigned)kNullSlot * 16u;
         int qalive = 15;  // quadrants that still have an unfinished pixel (wave-uniform)
         for (int base = 0; qalive && base < n; base += 64) {
             // quadrant mask of this lane's Gaussian: which live 8x8 quadrants its alpha >= 1/255 box can reach
@@ -990,25 +1041,37 @@ __device__ __forceinline__ void render_tile(const Params &p, WaveLds &L, int ite
                 qm = (int)(hx0 & hy0) | ((int)(hx1 & hy0) << 1) | ((int)(hx0 & hy1) << 2) | ((int)(hx1 & hy1) << 3);
                 qm &= qalive;
             }
-            // every lane stages its record at its own (= sorted) position; the four ballots are the quadrants' lists
+            // every lane stages its record at its own (= sorted) slot, moved into the tile's frame:
+            // u = qa (x - px) + qb (y - py) = k0 - qa lx - qb ly with k0 = qa (x - X0) + qb (y - Y0); v likewise
             if (qm != 0) {
-                L.stage[0][lane] = g0;
-                L.stage[1][lane] = g1;
-                L.stage[2][lane] = g2;  // {b, 1/depth, box half extents}: stored whole, so no copy of it is made early
+                const float rx = g0.x - X0f, ry = g0.y - Y0f;
+                L.geo[lane] = make_float4(fmaf(g0.z, rx, g0.w * ry), g1.x * ry, g0.z, g0.w);
+                *reinterpret_cast<float2 *>(&L.geo2[lane]) = make_float2(g1.x, g1.y);
+                L.col[lane] = make_float4(g1.z, g1.w, g2.x, g2.y);
             }
+            // the four quadrant lists: a lane's entry goes to the position its bit has in the quadrant's ballot
             const unsigned long long m0 = __ballot(qm & 1), m1 = __ballot(qm & 2), m2 = __ballot(qm & 4),
                                      m3 = __ballot(qm & 8);
+            const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
+            auto put = [&](int q, unsigned long long m, int cnt, int bit) {
+                typedef __attribute__((address_space(3))) unsigned lds_u32w;
+                lds_u32w *list = (lds_u32w *)(uintptr_t)(lists_base + (unsigned)q * (kListStride * 4u));
+                if (qm & bit)
+                    list[__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = my_slot;
+                if (lane < kListTail) list[cnt + lane] = null_slot;
+            };
+            if (n0) put(0, m0, n0, 1);
+            if (n1) put(1, m1, n1, 2);
+            if (n2) put(2, m2, n2, 4);
+            if (n3) put(3, m3, n3, 8);
             wave_sync();
             // prefetch the next round's records while this one is blended
             if (base + 64 + lane < n) load_records(base + 64 + lane);
-#if AMAV_ABLATE == 3 || AMAV_ABLATE == 7 || AMAV_ABLATE == 8  /* diagnostic build: no blending at all */
-            if (false)
-#endif
-            if (m0 && !blend_quadrant<kInvDepth>(m0, L, pxf0, pyf0, T0, R0, G0, B0, D0)) qalive &= ~1;
-#if AMAV_ABLATE != 3 && AMAV_ABLATE != 7 && AMAV_ABLATE != 8
-            if (m1 && !blend_quadrant<kInvDepth>(m1, L, pxf1, pyf0, T1, R1, G1, B1, D1)) qalive &= ~2;
-            if (m2 && !blend_quadrant<kInvDepth>(m2, L, pxf0, pyf1, T2, R2, G2, B2, D2)) qalive &= ~4;
-            if (m3 && !blend_quadrant<kInvDepth>(m3, L, pxf1, pyf1, T3, R3, G3, B3, D3)) qalive &= ~8;
+#if AMAV_ABLATE != 3 && AMAV_ABLATE != 7  /* diagnostic builds: no blending at all */
+            if (n0 && !blend_quadrant<kInvDepth>(lists_base, (n0 + 1) >> 1, lxf0, lyf0, T0, R0, G0, B0, D0)) qalive &= ~1;
+            if (n1 && !blend_quadrant<kInvDepth>(lists_base + kListStride * 4u, (n1 + 1) >> 1, lxf1, lyf0, T1, R1, G1, B1, D1)) qalive &= ~2;
+            if (n2 && !blend_quadrant<kInvDepth>(lists_base + kListStride * 8u, (n2 + 1) >> 1, lxf0, lyf1, T2, R2, G2, B2, D2)) qalive &= ~4;
+            if (n3 && !blend_quadrant<kInvDepth>(lists_base + kListStride * 12u, (n3 + 1) >> 1, lxf1, lyf1, T3, R3, G3, B3, D3)) qalive &= ~8;
 #endif
             wave_sync();
         }
@@ -1029,9 +1092,6 @@ __device__ __forceinline__ void render_tile(const Params &p, WaveLds &L, int ite
                 bl = fminf(fmaxf(bl, 0.f), 1.f);
             }
             const size_t pid = ((size_t)f * p.H + py) * p.W + px;
-#if AMAV_ABLATE == 6 || AMAV_ABLATE == 8
-            if (r == 123.f)  /* diagnostic build: no tile stores */
-#endif
             reinterpret_cast<float4 *>(p.out_rgba)[pid] = make_float4(r, g, bl, 1.0f - Tq[q]);
             if (kInvDepth) p.out_inv_depth[pid] = Dq[q];
         }
@@ -1075,7 +1135,7 @@ __global__ __launch_bounds__(64, kRenderWavesPerSimd) void render_kernel(Params 
             // wave-uniform: keep the tile id (and everything derived from it) in scalar registers
             const int item = __builtin_amdgcn_readfirstlane(p.buf.queue[((size_t)q * kBuckets + b) * p.qcap + (i - acc)]);
             render_tile<kInvDepth>(p, lds, item, lane);
-#if AMAV_ABLATE != 5 && AMAV_ABLATE != 7 && AMAV_ABLATE != 8
+#if AMAV_ABLATE != 5 && AMAV_ABLATE != 7
             for (const int stop = min(e1, e0 + fill_chunk); e0 < stop; ++e0) fill_tile<kInvDepth>(p, p.buf.empty_list[e0], lane);
 #endif
             i = __builtin_amdgcn_readfirstlane(nxt);
@@ -1083,7 +1143,7 @@ __global__ __launch_bounds__(64, kRenderWavesPerSimd) void render_kernel(Params 
     }
     // the rest of this wave's background tiles (all of them when it had no tile to blend; every tile of the launch
     // when the instance regions overflowed: the caller must retry)
-#if AMAV_ABLATE != 5 && AMAV_ABLATE != 7 && AMAV_ABLATE != 8
+#if AMAV_ABLATE != 5 && AMAV_ABLATE != 7
     for (; e0 < e1; ++e0) fill_tile<kInvDepth>(p, p.buf.empty_list[e0], lane);
 #endif
 }

@@ -329,7 +329,8 @@ def test_measured_bounds_attention_is_hip_graph_capturable():
         assert torch.equal(out, want)
     ref = torch.nn.functional.scaled_dot_product_attention(
         *(t.view(B, S, H, D).transpose(1, 2).double() for t in (qkv[..., :i], qkv[..., i:2 * i], qkv[..., 2 * i:])))
-    assert float((out.view(B, S, H, D).transpose(1, 2).double() - ref).abs().max()) <= 2e-5
+    # inputs were scaled by 3 (|v| up to 13): the kernel's 2e-5 bar is relative to the output's magnitude
+    assert float((out.view(B, S, H, D).transpose(1, 2).double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
 
 
 def test_refiner_convolution_is_hip_graph_capturable():
