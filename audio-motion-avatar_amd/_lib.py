@@ -6,7 +6,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libamav_hip.so")
+# AMAV_LIB: another build of the SAME library (tools/ablate_render.sh builds diagnostic variants of the blend kernel
+# with -DAMAV_ABLATE=n); never a different implementation -- the symbol table is checked against include/amav.h either way
+LIB_PATH = os.environ.get("AMAV_LIB") or os.path.join(_HERE, "csrc", "libamav_hip.so")
 
 c_float_p = ctypes.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 

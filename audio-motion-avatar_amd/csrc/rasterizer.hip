@@ -13,19 +13,20 @@
 //                  host round trip (upstream syncs to read the instance count).
 //   sort_big       persistent blocks sort the tile lists longer than 512 keys: an exact bucket sort in LDS (<= 2 K
 //                  keys), a bitonic network for clustered depths or longer lists.
-//   render_kernel  ONE WAVEFRONT PER TILE (and per workgroup): loads its keys and sorts them in its LDS slice -- rank
-//                  sort up to 64 keys, an exact depth-bucket sort up to 512 (comparison sorts when the depths are
-//                  too clustered); keys are unique, so the order equals upstream's stable radix sort by
-//                  (tile, depth) -- then blends 4 pixels per lane, one in each 8x8 quadrant of the tile.  Gaussians
-//                  are staged 64 at a time through LDS; the staging lane tests the Gaussian's exact alpha >= 1/255
-//                  bounding box against the four quadrants, drops Gaussians that cannot touch the tile (ballot +
-//                  mbcnt compaction) and records a 4-bit quadrant mask, so the wave only evaluates quadrants the
-//                  Gaussian can reach (wave-uniform branches; skipped evaluations are ones the reference would
-//                  reject with alpha < 1/255, so the output is unchanged).  Early-out by __any(); the state of a
-//                  finished pixel is the sign of its transmittance.  Output is pixel-interleaved RGBA, so every
-//                  store instruction writes eight full 128-byte lines.  Tiles reach the waves through eight work
-//                  queues (one per XCD: tile-row bands, rotating with the frame) bucketed by list length and
-//                  dispatched longest first.
+//   render_kernel  PERSISTENT WAVES, one tile at a time per wave (one wave per workgroup): the tile's keys are sorted
+//                  in the wave's LDS slice -- rank sort up to 64 keys, an exact depth-bucket sort up to 512
+//                  (comparison sorts when the depths are too clustered); keys are unique, so the order equals
+//                  upstream's stable radix sort by (tile, depth) -- then blended 4 pixels per lane, one in each 8x8
+//                  quadrant of the tile.  Gaussians are staged 64 at a time through LDS, moved into the tile's frame;
+//                  the staging lane tests the Gaussian's exact alpha >= 1/255 bounding box against the four
+//                  quadrants and enters the record's LDS address into the lists of the quadrants it can reach
+//                  (ballot + mbcnt), so a quadrant's blend loop walks a dense address list and skips only
+//                  evaluations the reference would reject with alpha < 1/255.  The blend loop itself is hand-scheduled
+//                  assembly (17 vector instructions per pixel and Gaussian, LDS reads pipelined with counted waits).
+//                  The next tile's start-up chain (queue entry -> keys -> sort -> first records) runs under the
+//                  current tile's blending.  Output is pixel-interleaved RGBA, so every store instruction writes
+//                  full 128-byte lines.  Tiles reach the waves through eight work queues (one per XCD: tile-row
+//                  bands, rotating with the frame) bucketed by list length and dispatched longest first.
 #include <algorithm>
 #include <cstddef>
 #include <cstdlib>
@@ -39,7 +40,7 @@ namespace raster {
 #define AMAV_ABLATE 0  /* diagnostic builds of the blend kernel only (tools/): never set in the product */
 #endif
 constexpr int kTile = AMAV_TILE;
-constexpr int kRenderWavesPerSimd = 5;  // blend kernel: one-wave workgroups resident per SIMD (register cap)
+constexpr int kRenderWavesPerSimd = 4;  // blend kernel: one-wave workgroups resident per SIMD (register cap)
 constexpr int kSortCap = 512;      // keys a wave sorts in its LDS slice (4 KiB); longer lists go to sort_big
 constexpr int kBigLdsCap = 2048;   // keys a sort_big block sorts in LDS (16 KiB); longer lists are sorted in place
 constexpr int kBigBlocks = 1280;
@@ -72,7 +73,7 @@ struct Buffers {
     unsigned long long *keys;  // [F * cap_per_frame]
     unsigned *sorted;          // [F * cap_per_frame] blend order of the big tiles only
     int *big_list;             // [F*T] (frame * T + tile) of lists longer than kSortCap
-    int *queue;                // [kQueues][kBuckets][qcap] (frame * T + tile) of non-empty tiles
+    int4 *queue;               // [kQueues][kBuckets][qcap] non-empty tiles: {frame * T + tile, list offset in the frame's region, list length, 0}
     int *empty_list;           // [F*T] (frame * T + tile) of empty tiles
     Status *status;
 };
@@ -91,7 +92,7 @@ static Buffers carve(void *ws, int F, int N, int gx, int gy, long long cap, size
     b.keys = c.take<unsigned long long>((size_t)cap);
     b.sorted = c.take<unsigned>((size_t)cap);
     b.big_list = c.take<int>((size_t)F * T);
-    b.queue = c.take<int>((size_t)kQueues * kBuckets * queue_capacity(F, gx, gy));
+    b.queue = c.take<int4>((size_t)kQueues * kBuckets * queue_capacity(F, gx, gy));
     b.empty_list = c.take<int>((size_t)F * T);
     if (bytes) *bytes = c.total();
     return b;
@@ -117,6 +118,15 @@ struct Params {
 
 __device__ __forceinline__ const float *at(const amav_attr &a, int f, int i) {
     return a.ptr + (long long)f * a.frame_stride + (long long)i * a.elem_stride;
+}
+
+// The value of `x`, opaque to the optimiser: what is derived from the result cannot be hoisted out of the enclosing loop.
+// The persistent kernels below are one long loop around a lot of inlined code; left alone, the compiler hoists every
+// lane-derived address and predicate out of it and then spills them (90 registers to scratch, whose reloads are
+// vector-memory operations that queue behind the wave's stores): recomputing them costs a few instructions per tile.
+__device__ __forceinline__ int opaque(int x) {
+    asm volatile("" : "+v"(x));
+    return x;
 }
 
 __device__ __forceinline__ void wave_sync() {
@@ -399,7 +409,7 @@ __global__ __launch_bounds__(1024) void bin_kernel(Params p) {
             if (kind == kBuckets)
                 p.buf.empty_list[pos] = f * p.T + t0 + k;
             else
-                p.buf.queue[((size_t)qi * kBuckets + kind) * p.qcap + pos] = f * p.T + t0 + k;
+                p.buf.queue[((size_t)qi * kBuckets + kind) * p.qcap + pos] = make_int4(f * p.T + t0 + k, cursor[t0 + k], c, 0);
         }
     if (threadIdx.x == 0) {
         off[p.T] = total;
@@ -916,235 +926,539 @@ __device__ __forceinline__ bool blend_quadrant(unsigned list, int groups, float 
         if (p.stamps && lane == 0) p.stamps[(size_t)item * 6 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
 
-// Background for a tile without Gaussians: colour = bg, alpha = 0 (and inverse depth 0).
-template <bool kInvDepth>
-__device__ __forceinline__ void fill_tile(const Params &p, int item, int lane) {
+// Background for the tiles without Gaussians: colour = bg, alpha = 0 (and inverse depth 0).  A wave owns the slice
+// [e0, e1) of the empty list and writes it a few tiles at a time between its blended tiles.  The tile ids are fetched
+// 64 at a time (one per lane) and decoded in the lanes, so a tile costs two scalar reads of lane registers and its
+// stores -- round 2 loaded every id just before its tile: one dependent global round trip per 4 KiB written, 40 of them
+// in a row per wave, which is what kept the stores from hiding under the blending (the kernel ran 0.12 ms longer with
+// the background than without: the full fill time of the 0.85 GB at the chip's fill rate).
+struct FillCursor {
+    int next, end;     // slice of the empty list not yet fetched
+    int have, pos;     // lanes of the current batch, next lane to write
+    long long origin;  // per lane: pixel index of the tile's first pixel
+    int xy;            // per lane: X0 | Y0 << 16
+};
+
+__device__ __forceinline__ void fill_fetch(const Params &p, FillCursor &c, int lane) {
+    c.have = min(64, c.end - c.next);
+    c.pos = 0;
+    if (c.have <= 0) return;
+    const int item = p.buf.empty_list[c.next + min(lane, c.have - 1)];
+    c.next += c.have;
     const int f = item / p.T, t = item - f * p.T;
-    const int X0 = (t % p.gx) * kTile, Y0 = (t / p.gx) * kTile;
+    const int ty = t / p.gx, tx = t - ty * p.gx;
+    c.xy = (tx * kTile) | ((ty * kTile) << 16);
+    c.origin = ((long long)f * p.H + ty * kTile) * p.W + tx * kTile;
+}
+
+// up to `count` tiles of the wave's slice
+template <bool kInvDepth>
+__device__ __forceinline__ void fill_some(const Params &p, FillCursor &c, int count, int lane) {
     float r = p.bg[0], g = p.bg[1], bl = p.bg[2];
     if (p.clamp_output) {
         r = fminf(fmaxf(r, 0.f), 1.f);
         g = fminf(fmaxf(g, 0.f), 1.f);
         bl = fminf(fmaxf(bl, 0.f), 1.f);
     }
+    const float4 px_bg = make_float4(r, g, bl, 0.0f);
+    lane = opaque(lane);
     // lane -> (column lane & 15, rows (lane >> 4) + 4k): every store instruction covers four full 256-byte tile rows
-    const int px = X0 + (lane & 15);
+    const int cx = lane & 15, cy = lane >> 4;
+    while (count > 0) {
+        if (c.pos >= c.have) {
+            if (c.next >= c.end) return;
+            fill_fetch(p, c, lane);
+        }
+        const int todo = min(count, c.have - c.pos);
+        for (int j = c.pos; j < c.pos + todo; ++j) {
+            const int xy = __builtin_amdgcn_readlane(c.xy, j);
+            const long long origin = ((long long)__builtin_amdgcn_readlane((int)(c.origin >> 32), j) << 32) |
+                                     (unsigned)__builtin_amdgcn_readlane((int)c.origin, j);
+            const int X0 = xy & 0xffff, Y0 = xy >> 16;
+            const bool in_x = X0 + cx < p.W;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (in_x && Y0 + cy + 4 * k < p.H) {
+                    const long long pid = origin + (long long)(cy + 4 * k) * p.W + cx;
+                    reinterpret_cast<float4 *>(p.out_rgba)[pid] = px_bg;
+                    if (kInvDepth) p.out_inv_depth[pid] = 0.0f;
+                }
+            }
+        }
+        c.pos += todo;
+        count -= todo;
+    }
+}
+
+// The next tile of the current batch (the caller checks c.pos < c.have): no load, so it can sit inside the blend rounds.
+template <bool kInvDepth>
+__device__ __forceinline__ void fill_tile_at(const Params &p, FillCursor &c, int lane) {
+    const int j = c.pos++;
+    const int xy = __builtin_amdgcn_readlane(c.xy, j);
+    const long long origin = ((long long)__builtin_amdgcn_readlane((int)(c.origin >> 32), j) << 32) |
+                             (unsigned)__builtin_amdgcn_readlane((int)c.origin, j);
+    const int X0 = xy & 0xffff, Y0 = xy >> 16;
+    float r = p.bg[0], g = p.bg[1], bl = p.bg[2];
+    if (p.clamp_output) {
+        r = fminf(fmaxf(r, 0.f), 1.f);
+        g = fminf(fmaxf(g, 0.f), 1.f);
+        bl = fminf(fmaxf(bl, 0.f), 1.f);
+    }
+    const int cx = lane & 15, cy = lane >> 4;
+    const bool in_x = X0 + cx < p.W;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int py = Y0 + (lane >> 4) + 4 * k;
-        if (px < p.W && py < p.H) {
-            const size_t pid = ((size_t)f * p.H + py) * p.W + px;
+        if (in_x && Y0 + cy + 4 * k < p.H) {
+            const long long pid = origin + (long long)(cy + 4 * k) * p.W + cx;
             reinterpret_cast<float4 *>(p.out_rgba)[pid] = make_float4(r, g, bl, 0.0f);
             if (kInvDepth) p.out_inv_depth[pid] = 0.0f;
         }
     }
 }
 
-// One non-empty tile, one wavefront.
-template <bool kInvDepth>
-__device__ __forceinline__ void render_tile(const Params &p, WaveLds &L, int item, int lane) {
-    const int f = item / p.T, t = item - f * p.T;
-    AMAV_STAMP(0);
-    const int tx = t % p.gx, ty = t / p.gx;
-    const int X0 = tx * kTile, Y0 = ty * kTile;
-    // this lane's four pixels: (X0 + 8*qx + lx, Y0 + 8*qy + ly), quadrant q = qx + 2*qy
-    const int lx = lane & 7, ly = lane >> 3;
-    // pixel coordinates relative to the tile origin (blend_px works in the tile's frame)
-    float lxf0 = (float)lx, lxf1 = (float)(8 + lx), lyf0 = (float)ly, lyf1 = (float)(8 + ly);
-    asm volatile("" : "+v"(lxf0), "+v"(lxf1), "+v"(lyf0), "+v"(lyf1));  // keep them in registers (no re-convert)
-    const bool in0 = X0 + lx < p.W, in1 = X0 + 8 + lx < p.W, inr0 = Y0 + ly < p.H, inr1 = Y0 + 8 + ly < p.H;
+// ---- tile preparation under the previous tile
+struct TileRef {
+    int item, beg, n;  // frame * T + tile, list offset inside the frame's key region, list length (all wave-uniform)
+};
 
-    float T0 = (in0 & inr0) ? 1.f : -1.f, T1 = (in1 & inr0) ? 1.f : -1.f;
-    float T2 = (in0 & inr1) ? 1.f : -1.f, T3 = (in1 & inr1) ? 1.f : -1.f;
-    float R0 = 0.f, G0 = 0.f, B0 = 0.f, D0 = 0.f, R1 = 0.f, G1 = 0.f, B1 = 0.f, D1 = 0.f;
-    float R2 = 0.f, G2 = 0.f, B2 = 0.f, D2 = 0.f, R3 = 0.f, G3 = 0.f, B3 = 0.f, D3 = 0.f;
+constexpr int kPrepCap = 256;   // lists up to this length are sorted while the previous tile is still blending
+constexpr int kPrepBuckets = 256;
 
-    const int *off = p.buf.tile_off + (size_t)f * (p.T + 1);
-    const int beg = __builtin_amdgcn_readfirstlane(off[t]);
-    const int n = __builtin_amdgcn_readfirstlane(off[t + 1]) - beg;
-    AMAV_STAMP(1);
-    if (p.stamps && lane == 0) p.stamps[(size_t)item * 6 + 5] = (unsigned long long)n;
-    {
-        const unsigned long long *keys = p.buf.keys + (size_t)f * p.cap_per_frame + beg;
-        const unsigned *order_g = p.buf.sorted + (size_t)f * p.cap_per_frame + beg;  // long lists only
-        unsigned *order_l = reinterpret_cast<unsigned *>(L.keys);
-        const bool local = n <= kSortCap;
-        if (local) {
-            unsigned *cnt = reinterpret_cast<unsigned *>(L.geo);  // the staging buffers are idle while sorting
-            bool done = false;
-            if (n <= 64) {
-                for (int k = lane; k < n; k += 64) L.keys[k] = keys[k];
-                wave_sync();
-            } else if (n <= 128)
-                done = bucket_sort<2>(keys, L.keys, cnt, order_l, n, lane);
-            else if (n <= 192)
-                done = bucket_sort<3>(keys, L.keys, cnt, order_l, n, lane);
-            else if (n <= 256)
-                done = bucket_sort<4>(keys, L.keys, cnt, order_l, n, lane);
-            else if (n <= 384)
-                done = bucket_sort<6>(keys, L.keys, cnt, order_l, n, lane);
-            else
-                done = bucket_sort<8>(keys, L.keys, cnt, order_l, n, lane);
-            if (!done) {  // short list, or depths too clustered for buckets: comparison sorts on the keys in LDS
-                if (n <= 64)
-                    rank_sort<1>(L.keys, order_l, n, lane);
-                else if (n <= 128)
-                    rank_sort<2>(L.keys, order_l, n, lane);
-                else if (n <= 192)
-                    rank_sort<3>(L.keys, order_l, n, lane);
-                else if (n <= 256)
-                    rank_sort<4>(L.keys, order_l, n, lane);
-                else
-                    wave_bitonic_sort(L.keys, order_l, n, lane);
-            }
-        }
-        AMAV_STAMP(2);
-        // the sorts used the staging buffers as scratch: (re)write the null record (log2(opacity) = -inf blends nothing)
-        if (lane == 0) {
-            L.geo[kNullSlot] = make_float4(0.f, 0.f, 0.f, 0.f);
-            L.col[kNullSlot] = make_float4(0.f, 0.f, 0.f, 0.f);
-            L.geo2[kNullSlot] = make_float4(0.f, -__builtin_inff(), 0.f, 0.f);
-        }
-
-        // ---- blend, 64 Gaussians per staging round
-        const float4 *geom = p.buf.geom + (size_t)f * p.N * 3;
-        float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0, g2 = g0;
-        // blend order of position k: from this wave's LDS slice, or (lists longer than kSortCap) from sort_big's output.
-        // Two explicit paths: a select between an LDS and a global pointer becomes a FLAT load, whose completion the
-        // hardware can only express as "everything done" (vmcnt(0) + lgkmcnt(0)).
-        typedef __attribute__((address_space(3))) const unsigned lds_u32;
-        lds_u32 *order_lds = (lds_u32 *)order_l;
-        auto load_records = [&](int k) {
-            unsigned id;
-            if (local)
-                id = order_lds[k];
-            else
-                id = order_g[k];
-            const float4 *g = geom + (size_t)id * 3;
-            g0 = g[0], g1 = g[1], g2 = g[2];
-        };
-        if (lane < n) load_records(lane);
-        const float X0f = (float)X0, Y0f = (float)Y0;
-        // LDS byte addresses (the quadrant lists hold addresses, so the blend loop does no address arithmetic)
-        const unsigned stage_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)&L.geo[0];
-        const unsigned lists_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)&L.keys[kSortCap / 2];
-        const unsigned my_slot = stage_base + (unsigned)lane * 16u, null_slot = stage_base + (unsigned)kNullSlot * 16u;
-        int qalive = 15;  // quadrants that still have an unfinished pixel (wave-uniform)
-        for (int base = 0; qalive && base < n; base += 64) {
-            // quadrant mask of this lane's Gaussian: which live 8x8 quadrants its alpha >= 1/255 box can reach
-            int qm = 0;
-            if (base + lane < n) {
-                const bool hx0 = (g0.x + g2.z >= X0f) & (g0.x - g2.z <= X0f + 7.f);
-                const bool hx1 = (g0.x + g2.z >= X0f + 8.f) & (g0.x - g2.z <= X0f + 15.f);
-                const bool hy0 = (g0.y + g2.w >= Y0f) & (g0.y - g2.w <= Y0f + 7.f);
-                const bool hy1 = (g0.y + g2.w >= Y0f + 8.f) & (g0.y - g2.w <= Y0f + 15.f);
-                qm = (int)(hx0 & hy0) | ((int)(hx1 & hy0) << 1) | ((int)(hx0 & hy1) << 2) | ((int)(hx1 & hy1) << 3);
-                qm &= qalive;
-            }
-            // every lane stages its record at its own (= sorted) slot, moved into the tile's frame:
-            // u = qa (x - px) + qb (y - py) = k0 - qa lx - qb ly with k0 = qa (x - X0) + qb (y - Y0); v likewise
-            if (qm != 0) {
-                const float rx = g0.x - X0f, ry = g0.y - Y0f;
-                L.geo[lane] = make_float4(fmaf(g0.z, rx, g0.w * ry), g1.x * ry, g0.z, g0.w);
-                *reinterpret_cast<float2 *>(&L.geo2[lane]) = make_float2(g1.x, g1.y);
-                L.col[lane] = make_float4(g1.z, g1.w, g2.x, g2.y);
-            }
-            // the four quadrant lists: a lane's entry goes to the position its bit has in the quadrant's ballot
-            const unsigned long long m0 = __ballot(qm & 1), m1 = __ballot(qm & 2), m2 = __ballot(qm & 4),
-                                     m3 = __ballot(qm & 8);
-            const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
-            auto put = [&](int q, unsigned long long m, int cnt, int bit) {
-                typedef __attribute__((address_space(3))) unsigned lds_u32w;
-                lds_u32w *list = (lds_u32w *)(uintptr_t)(lists_base + (unsigned)q * (kListStride * 4u));
-                if (qm & bit)
-                    list[__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = my_slot;
-                if (lane < kListTail) list[cnt + lane] = null_slot;
-            };
-            if (n0) put(0, m0, n0, 1);
-            if (n1) put(1, m1, n1, 2);
-            if (n2) put(2, m2, n2, 4);
-            if (n3) put(3, m3, n3, 8);
-            wave_sync();
-            // prefetch the next round's records while this one is blended
-            if (base + 64 + lane < n) load_records(base + 64 + lane);
-#if AMAV_ABLATE != 3 && AMAV_ABLATE != 7  /* diagnostic builds: no blending at all */
-            if (n0 && !blend_quadrant<kInvDepth>(lists_base, (n0 + 1) >> 1, lxf0, lyf0, T0, R0, G0, B0, D0)) qalive &= ~1;
-            if (n1 && !blend_quadrant<kInvDepth>(lists_base + kListStride * 4u, (n1 + 1) >> 1, lxf1, lyf0, T1, R1, G1, B1, D1)) qalive &= ~2;
-            if (n2 && !blend_quadrant<kInvDepth>(lists_base + kListStride * 8u, (n2 + 1) >> 1, lxf0, lyf1, T2, R2, G2, B2, D2)) qalive &= ~4;
-            if (n3 && !blend_quadrant<kInvDepth>(lists_base + kListStride * 12u, (n3 + 1) >> 1, lxf1, lyf1, T3, R3, G3, B3, D3)) qalive &= ~8;
-#endif
-            wave_sync();
-        }
+// Exact (depth, id) order of n <= kPrepCap unique keys held in registers (k[m] = key lane + 64 m, ~0 beyond n): the
+// 32-bit ids land in order[0 .. n).  `slice` (n keys) and `order` may alias (ids overwrite the slice once every lane
+// has read it); `cnt` = kPrepBuckets / 2 + 1 words of scratch.  Same method as bucket_sort / rank_sort above.
+__device__ __forceinline__ void sort_prefetched(const unsigned long long (&k)[4], int n, unsigned long long *slice,
+                                                unsigned *cnt, unsigned *order, int lane) {
+    if (n <= 64) {
+        if (lane < n) slice[lane] = k[0];
+        wave_sync();
+        rank_sort<1>(slice, order, n, lane);
+        return;
     }
-
-    AMAV_STAMP(3);
-    // ---- write back: quadrant q of the wave = 8 rows x 128 B
-    const float Tq[4] = {fabsf(T0), fabsf(T1), fabsf(T2), fabsf(T3)};
-    const float Rq[4] = {R0, R1, R2, R3}, Gq[4] = {G0, G1, G2, G3}, Bq[4] = {B0, B1, B2, B3}, Dq[4] = {D0, D1, D2, D3};
+    unsigned dmin = 0xffffffffu, dmax = 0u;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int px = X0 + 8 * (q & 1) + lx, py = Y0 + 8 * (q >> 1) + ly;
-        if (px < p.W && py < p.H) {
-            float r = Rq[q] + Tq[q] * p.bg[0], g = Gq[q] + Tq[q] * p.bg[1], bl = Bq[q] + Tq[q] * p.bg[2];
-            if (p.clamp_output) {
-                r = fminf(fmaxf(r, 0.f), 1.f);
-                g = fminf(fmaxf(g, 0.f), 1.f);
-                bl = fminf(fmaxf(bl, 0.f), 1.f);
-            }
-            const size_t pid = ((size_t)f * p.H + py) * p.W + px;
-            reinterpret_cast<float4 *>(p.out_rgba)[pid] = make_float4(r, g, bl, 1.0f - Tq[q]);
-            if (kInvDepth) p.out_inv_depth[pid] = Dq[q];
+    for (int m = 0; m < 4; ++m) {
+        const unsigned d = (unsigned)(k[m] >> 32);
+        if (lane + 64 * m < n) dmin = min(dmin, d), dmax = max(dmax, d);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        dmin = min(dmin, (unsigned)__shfl_xor((int)dmin, o, 64));
+        dmax = max(dmax, (unsigned)__shfl_xor((int)dmax, o, 64));
+    }
+    const float scale = dmax > dmin ? (float)(kPrepBuckets - 1) / (float)(dmax - dmin) : 0.0f;
+    int b[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) b[m] = min(kPrepBuckets - 1, (int)((float)((unsigned)(k[m] >> 32) - dmin) * scale));
+    reinterpret_cast<uint2 *>(cnt)[lane] = make_uint2(0u, 0u);  // 128 words of two 16-bit counts
+    wave_sync();
+    unsigned pos[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        pos[m] = 0;
+        if (lane + 64 * m < n) {
+            const int sh = 16 * (b[m] & 1);
+            pos[m] = (atomicAdd(&cnt[b[m] >> 1], 1u << sh) >> sh) & 0xffffu;  // arrival index inside the bucket
         }
     }
-    AMAV_STAMP(4);
+    wave_sync();
+    const uint2 w = reinterpret_cast<uint2 *>(cnt)[lane];  // lane owns buckets 4 lane .. 4 lane + 3
+    unsigned c[4] = {w.x & 0xffffu, w.x >> 16, w.y & 0xffffu, w.y >> 16};
+    unsigned tot = 0, big = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned ci = c[i];
+        big = max(big, ci);
+        c[i] = tot;
+        tot += ci;
+    }
+    unsigned incl = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned up = (unsigned)__shfl_up((int)incl, o, 64);
+        if (lane >= o) incl += up;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) big = max(big, (unsigned)__shfl_xor((int)big, o, 64));
+    if (big > (unsigned)kBucketMax) {  // wave-uniform: clustered depths, comparison sort
+        wave_sync();
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            if (lane + 64 * m < n) slice[lane + 64 * m] = k[m];
+        wave_sync();
+        rank_sort<4>(slice, order, n, lane);
+        return;
+    }
+    const unsigned base = incl - tot;
+    reinterpret_cast<uint2 *>(cnt)[lane] = make_uint2((base + c[0]) | ((base + c[1]) << 16), (base + c[2]) | ((base + c[3]) << 16));
+    if (lane == 0) cnt[kPrepBuckets / 2] = (unsigned)n;  // start of the bucket past the last one
+    wave_sync();
+    unsigned st[4], sz[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        st[m] = (cnt[b[m] >> 1] >> (16 * (b[m] & 1))) & 0xffffu;
+        const int nb = b[m] + 1;
+        sz[m] = ((cnt[nb >> 1] >> (16 * (nb & 1))) & 0xffffu) - st[m];
+        if (lane + 64 * m < n) slice[st[m] + pos[m]] = k[m];
+    }
+    wave_sync();
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        unsigned r = pos[m];
+        if (lane + 64 * m < n && sz[m] > 1u) {  // order the bucket by the full key
+            r = 0;
+            for (unsigned j = 0; j < sz[m]; ++j) r += (unsigned)(slice[st[m] + j] < k[m]);
+        }
+        pos[m] = st[m] + r;
+    }
+    wave_sync();  // the ids overwrite the slice: every lane has finished reading it
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+        if (lane + 64 * m < n) order[pos[m]] = (unsigned)k[m];
+    wave_sync();
 }
 
 // Blend kernel: PERSISTENT waves (one wave per workgroup, the grid is what the chip holds at once).  The waves of
 // queue q (= blockIdx % 8: blocks are dealt round-robin over the XCDs, so an XCD keeps seeing the tile-row bands of
 // its own queue -- a placement assumption that only affects speed) walk the queue's buckets, which are ordered
 // LONGEST LISTS FIRST, so the kernel ends on the shortest tiles.  The first position of a wave is static; every later
-// one comes from the queue's cursor (one returning atomic per tile on one of eight words, issued a tile ahead so its
-// round trip hides under the blending: ~16 dequeues per microsecond and word, far below the ~88 a word sustains).
-// (Round 1 launched one workgroup per possible tile -- 256 000 of them for 51 000 non-empty tiles; the 205 000 waves
-// that only wrote background held an eighth of the wave slots.)  After each tile the wave writes a share of its
-// background tiles, so those stores stay spread over the whole kernel, under the VALU-bound blending.
+// one comes from the queue's cursor (one returning atomic per tile on one of eight words).
+//
+// A tile's start-up is a chain of dependent global round trips -- queue position -> queue entry -> keys -> (sort) ->
+// records of the first staging round -- and vector-memory operations of a wave complete in order, so a load issued
+// behind the wave's stores also waits for those to drain.  Round 2 paid that chain once per tile (18 us against 29 us
+// of blending).  Here every link is issued while an EARLIER tile is still blending, and ahead of that tile's stores:
+//     tile i starts              atomic for the position of tile i+2
+//     first round, after q0      that position has come back: request the queue entry of tile i+2
+//     last round, at its start   entry of tile i+1 (requested during tile i-1) is consumed: its keys go to registers
+//     last round, after q1       keys sorted in the id area of LDS (tile i has issued its last gather: the area is free),
+//                                records of tile i+1's first round requested (the prefetch registers are free as well)
+//     after q3                   wait for those records (they had q2 and q3 to arrive), THEN store tile i
+// Lists of 257..512 keys need the whole key area and are sorted at the start of their own tile, as is a wave's first tile.
+// Measured (250 frames, 512^2, 10 k Gaussians; tools/stamp_render.py): sort + range reads fall from 62 us to 20 us of a
+// wave's 500 us.
+//
+// Registers: the kernel is built for 4 waves per SIMD (128 registers).  At 5 (96 registers, round 2's setting) the
+// pipeline state on top of the blend loop's 27 fixed registers spills -- and a spill's reload is a vector-memory load
+// behind the stores, i.e. the very stall the pipeline removes (measured: 0.76 ms instead of 0.50).
 template <bool kInvDepth>
 __global__ __launch_bounds__(64, kRenderWavesPerSimd) void render_kernel(Params p) {
     __shared__ WaveLds lds;
+    WaveLds &L = lds;
     const int lane = threadIdx.x;
     const Status *st = p.buf.status;
-    const int nempty = st->nempty;
-    const int nw = gridDim.x, per = (nempty + nw - 1) / nw;
-    int e0 = min(nempty, (int)blockIdx.x * per);
-    const int e1 = min(nempty, e0 + per);
-    if (!st->overflow) {
-        const int q = blockIdx.x % kQueues, stride = gridDim.x / kQueues;
-        int total = 0;
-        for (int b = 0; b < kBuckets; ++b) total += st->qcount[q][b];
+    const int q = blockIdx.x % kQueues, stride = gridDim.x / kQueues;
+    // ---- background: every wave owns a slice of the empty list and writes it a few tiles per staging round, right
+    // after the round's records have been consumed and before the next round's are requested.  Vector-memory operations
+    // of a wave complete in order, so a wave waits for its stores whenever it next needs a loaded value; placed there,
+    // that next wait is a whole round of blending away.  (Measured alternatives: stores at the end of each tile, between
+    // quadrants, or by dedicated fill-first waves all cost the full fill time of 0.12 ms -- one wave sustains only
+    // ~4 GB/s of stores, 63 operations in flight at the ~15 us write latency of a saturated chip, so the background
+    // needs most of the chip's waves, thinly.)
+    FillCursor fill;
+    {
+        const int nempty = st->nempty;
+        const int per = (nempty + (int)gridDim.x - 1) / (int)gridDim.x;
+        fill.next = min(nempty, (int)blockIdx.x * per);
+        fill.end = min(nempty, fill.next + per);
+        fill.have = fill.pos = 0;
+        fill.origin = 0, fill.xy = 0;
+    }
+    // The queue's bucket table, read ONCE: lane b holds where bucket b starts and ends among the queue's positions.
+    // (Looked up in memory per tile, the walk was a chain of up to 17 dependent loads of the status block -- which the
+    // kernel also updates atomically, so nothing could be kept in registers -- each queued behind the wave's stores.)
+    int bucket_end = (lane < kBuckets && !st->overflow) ? st->qcount[q][lane] : 0;
+    const int bucket_len = bucket_end;
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) {  // kBuckets <= 32 lanes carry the table
+        const int o = __shfl_up(bucket_end, d, 64);
+        if (lane >= d) bucket_end += o;
+    }
+    const int bucket_start = bucket_end - bucket_len;
+    const int total = __builtin_amdgcn_readlane(bucket_end, kBuckets - 1);
+    int i_cur = blockIdx.x / kQueues;  // first round: static; afterwards the queue's shared cursor
+    if (i_cur < total) {
         // expected tiles per wave, to spread this wave's background tiles over its blended ones
         const int expect = max(1, (total + stride - 1) / stride);
-        const int fill_chunk = (e1 - e0 + expect - 1) / expect;
+        const int fill_chunk = (fill.end - fill.next + expect - 1) / expect;
         int *next = const_cast<int *>(&st->next[q][0]);
-        int i = blockIdx.x / kQueues;  // first round: static; afterwards the queue's shared cursor
-        while (i < total) {
-            // take the following position now: the atomic's round trip hides under this tile
-            int nxt = 0;
-            if (lane == 0) nxt = stride + atomicAdd(next, 1);
-            int b = 0, acc = 0;
-            while (i >= acc + st->qcount[q][b]) acc += st->qcount[q][b++];  // i < total: b stays inside the table
-            // wave-uniform: keep the tile id (and everything derived from it) in scalar registers
-            const int item = __builtin_amdgcn_readfirstlane(p.buf.queue[((size_t)q * kBuckets + b) * p.qcap + (i - acc)]);
-            render_tile<kInvDepth>(p, lds, item, lane);
+        const int4 *queue_q = p.buf.queue + (size_t)q * kBuckets * p.qcap;
+        auto entry_of = [&](int i) {  // i < total (wave-uniform): the bucket whose range holds position i
+            const int b = __popcll(__ballot(lane < kBuckets && i >= bucket_end));
+            const int first = __builtin_amdgcn_readlane(bucket_start, b);
+            return queue_q + (size_t)b * p.qcap + (i - first);
+        };
+        unsigned *order_l = reinterpret_cast<unsigned *>(L.keys);
+        typedef __attribute__((address_space(3))) const unsigned lds_u32;
+        lds_u32 *order_lds = (lds_u32 *)order_l;
+        unsigned *prep_cnt = reinterpret_cast<unsigned *>(&L.keys[kSortCap / 2]);  // lists 0 and 1: idle after quadrant 1
+        // LDS byte addresses (the quadrant lists hold addresses, so the blend loop does no address arithmetic)
+        const unsigned stage_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)&L.geo[0];
+        const unsigned lists_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)&L.keys[kSortCap / 2];
+        const unsigned null_slot = stage_base + (unsigned)kNullSlot * 16u;
+        auto write_null_record = [&]() {  // log2(opacity) = -inf blends nothing
+            if (lane == 0) {
+                L.geo[kNullSlot] = make_float4(0.f, 0.f, 0.f, 0.f);
+                L.col[kNullSlot] = make_float4(0.f, 0.f, 0.f, 0.f);
+                L.geo2[kNullSlot] = make_float4(0.f, -__builtin_inff(), 0.f, 0.f);
+            }
+        };
+        write_null_record();
 #if AMAV_ABLATE != 5 && AMAV_ABLATE != 7
-            for (const int stop = min(e1, e0 + fill_chunk); e0 < stop; ++e0) fill_tile<kInvDepth>(p, p.buf.empty_list[e0], lane);
+        fill_fetch(p, fill, lane);
 #endif
-            i = __builtin_amdgcn_readfirstlane(nxt);
+        int idx_v = 0;
+        if (lane == 0) idx_v = stride + atomicAdd(next, 1);
+        const int4 e0 = *entry_of(i_cur);
+        TileRef cur = {__builtin_amdgcn_readfirstlane(e0.x), __builtin_amdgcn_readfirstlane(e0.y),
+                       __builtin_amdgcn_readfirstlane(e0.z)};
+        bool ready = false;  // cur's blend order is in LDS and its first records are on their way
+        float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0, g2 = g0;
+        int i_next = __builtin_amdgcn_readfirstlane(idx_v);
+        int4 e_next = make_int4(0, 0, 0, 0);
+        if (i_next < total) e_next = *entry_of(i_next);
+        for (;;) {
+            const int ln = opaque(lane);  // per-tile copy of the lane id (see opaque())
+            // the position after next: the atomic's round trip hides under this tile
+            int idx2 = 0;
+            if (ln == 0) idx2 = stride + atomicAdd(next, 1);
+            int4 e_after = make_int4(0, 0, 0, 0);  // its queue entry, requested after the first quadrant below
+            const int item = cur.item, n = cur.n;
+            const unsigned my_slot = stage_base + (unsigned)ln * 16u;
+            const int f = item / p.T, t = item - f * p.T;
+            AMAV_STAMP(0);
+            const int tx = t % p.gx, ty = t / p.gx;
+            const int X0 = tx * kTile, Y0 = ty * kTile;
+            const unsigned *order_g = p.buf.sorted + (size_t)f * p.cap_per_frame + cur.beg;  // long lists only
+            const float4 *geom = p.buf.geom + (size_t)f * p.N * 3;
+            const bool local = n <= kSortCap;
+            if (p.stamps && ln == 0) p.stamps[(size_t)item * 6 + 5] = (unsigned long long)n;
+            // blend order of position k: from this wave's LDS slice, or (lists longer than kSortCap) from sort_big's output.
+            // Two explicit paths: a select between an LDS and a global pointer becomes a FLAT load, whose completion the
+            // hardware can only express as "everything done" (vmcnt(0) + lgkmcnt(0)).
+            auto load_records = [&](int k) {
+                unsigned id;
+                if (local)
+                    id = order_lds[k];
+                else
+                    id = order_g[k];
+                const float4 *g = geom + (size_t)id * 3;
+                g0 = g[0], g1 = g[1], g2 = g[2];
+            };
+            AMAV_STAMP(1);
+            if (!ready) {  // not prepared under the previous tile: the wave's first tile, lists of 257 .. 512 keys
+                const unsigned long long *keys = p.buf.keys + (size_t)f * p.cap_per_frame + cur.beg;
+                if (local) {
+                    unsigned *cnt = reinterpret_cast<unsigned *>(L.geo);  // the staging buffers are idle while sorting
+                    bool done = false;
+                    if (n <= 64) {
+                        for (int k = ln; k < n; k += 64) L.keys[k] = keys[k];
+                        wave_sync();
+                    } else if (n <= 128)
+                        done = bucket_sort<2>(keys, L.keys, cnt, order_l, n, ln);
+                    else if (n <= 192)
+                        done = bucket_sort<3>(keys, L.keys, cnt, order_l, n, ln);
+                    else if (n <= 256)
+                        done = bucket_sort<4>(keys, L.keys, cnt, order_l, n, ln);
+                    else if (n <= 384)
+                        done = bucket_sort<6>(keys, L.keys, cnt, order_l, n, ln);
+                    else
+                        done = bucket_sort<8>(keys, L.keys, cnt, order_l, n, ln);
+                    if (!done) {  // short list, or depths too clustered for buckets: comparison sorts on the keys in LDS
+                        if (n <= 64)
+                            rank_sort<1>(L.keys, order_l, n, ln);
+                        else if (n <= 128)
+                            rank_sort<2>(L.keys, order_l, n, ln);
+                        else if (n <= 192)
+                            rank_sort<3>(L.keys, order_l, n, ln);
+                        else if (n <= 256)
+                            rank_sort<4>(L.keys, order_l, n, ln);
+                        else
+                            wave_bitonic_sort(L.keys, order_l, n, ln);
+                    }
+                    write_null_record();  // the sorts used the staging buffers as scratch
+                }
+                if (ln < n) load_records(ln);
+            }
+            AMAV_STAMP(2);
+
+            // this ln's four pixels: (X0 + 8*qx + lx, Y0 + 8*qy + ly), quadrant q = qx + 2*qy
+            const int lx = ln & 7, ly = ln >> 3;
+            // pixel coordinates relative to the tile origin (the blend works in the tile's frame)
+            float lxf0 = (float)lx, lxf1 = (float)(8 + lx), lyf0 = (float)ly, lyf1 = (float)(8 + ly);
+            asm volatile("" : "+v"(lxf0), "+v"(lxf1), "+v"(lyf0), "+v"(lyf1));  // keep them in registers (no re-convert)
+            const bool in0 = X0 + lx < p.W, in1 = X0 + 8 + lx < p.W, inr0 = Y0 + ly < p.H, inr1 = Y0 + 8 + ly < p.H;
+            float T0 = (in0 & inr0) ? 1.f : -1.f, T1 = (in1 & inr0) ? 1.f : -1.f;
+            float T2 = (in0 & inr1) ? 1.f : -1.f, T3 = (in1 & inr1) ? 1.f : -1.f;
+            float R0 = 0.f, G0 = 0.f, B0 = 0.f, D0 = 0.f, R1 = 0.f, G1 = 0.f, B1 = 0.f, D1 = 0.f;
+            float R2 = 0.f, G2 = 0.f, B2 = 0.f, D2 = 0.f, R3 = 0.f, G3 = 0.f, B3 = 0.f, D3 = 0.f;
+            const float X0f = (float)X0, Y0f = (float)Y0;
+
+            // the next tile (filled in at the start of the last round)
+            TileRef nxt = {0, 0, 0};
+            bool ready_next = false;
+            const float4 *geom_next = geom;
+
+            int qalive = 15;  // quadrants that still have an unfinished pixel (wave-uniform)
+            int fill_left = fill_chunk;                                       // background tiles owed by this tile ...
+            const int fill_round = (fill_chunk * 64 + n - 1) / max(n, 64) + 0;  // ... per staging round (ceil(n / 64) rounds)
+            // ---- blend, 64 Gaussians per staging round; one more pass ("drain") when the pixels finished early, so that
+            // the next tile's preparation has exactly one place in the code
+            for (int base = 0;; base += 64) {
+                const bool more = qalive != 0 && base < n;
+                const bool last = !more || base + 64 >= n;
+                int n0 = 0, n1 = 0, n2 = 0, n3 = 0;
+                // the next tile's keys / first id: live from the start of the last round to its quadrant 1 only
+                unsigned long long pk[4] = {~0ull, ~0ull, ~0ull, ~0ull};
+                unsigned idf = 0;
+                if (last) {
+                    // ---- next tile, step 1: its queue entry (fetched in the middle of the previous tile) -> its keys, into
+                    // registers (in the last round the record prefetch registers are idle, so they cost no extra ones)
+                    nxt.item = __builtin_amdgcn_readfirstlane(e_next.x);
+                    nxt.beg = __builtin_amdgcn_readfirstlane(e_next.y);
+                    nxt.n = __builtin_amdgcn_readfirstlane(e_next.z);
+                    if (nxt.n > 0) {
+                        const int fn = nxt.item / p.T;
+                        geom_next = p.buf.geom + (size_t)fn * p.N * 3;
+                        if (nxt.n <= kPrepCap) {
+                            const unsigned long long *kn = p.buf.keys + (size_t)fn * p.cap_per_frame + nxt.beg;
+#pragma unroll
+                            for (int m = 0; m < 4; ++m)
+                                if (ln + 64 * m < nxt.n) pk[m] = kn[ln + 64 * m];
+                        } else if (nxt.n > kSortCap) {
+                            if (ln < nxt.n) idf = p.buf.sorted[(size_t)fn * p.cap_per_frame + nxt.beg + ln];
+                        }
+                    }
+                }
+                if (more) {
+                    // quadrant mask of this ln's Gaussian: which live 8x8 quadrants its alpha >= 1/255 box can reach
+                    int qm = 0;
+                    if (base + ln < n) {
+                        const bool hx0 = (g0.x + g2.z >= X0f) & (g0.x - g2.z <= X0f + 7.f);
+                        const bool hx1 = (g0.x + g2.z >= X0f + 8.f) & (g0.x - g2.z <= X0f + 15.f);
+                        const bool hy0 = (g0.y + g2.w >= Y0f) & (g0.y - g2.w <= Y0f + 7.f);
+                        const bool hy1 = (g0.y + g2.w >= Y0f + 8.f) & (g0.y - g2.w <= Y0f + 15.f);
+                        qm = (int)(hx0 & hy0) | ((int)(hx1 & hy0) << 1) | ((int)(hx0 & hy1) << 2) | ((int)(hx1 & hy1) << 3);
+                        qm &= qalive;
+                    }
+                    // every ln stages its record at its own (= sorted) slot, moved into the tile's frame:
+                    // u = qa (x - px) + qb (y - py) = k0 - qa lx - qb ly with k0 = qa (x - X0) + qb (y - Y0); v likewise
+                    if (qm != 0) {
+                        const float rx = g0.x - X0f, ry = g0.y - Y0f;
+                        L.geo[ln] = make_float4(fmaf(g0.z, rx, g0.w * ry), g1.x * ry, g0.z, g0.w);
+                        *reinterpret_cast<float2 *>(&L.geo2[ln]) = make_float2(g1.x, g1.y);
+                        L.col[ln] = make_float4(g1.z, g1.w, g2.x, g2.y);
+                    }
+                    // the four quadrant lists: a ln's entry goes to the position its bit has in the quadrant's ballot
+                    const unsigned long long m0 = __ballot(qm & 1), m1 = __ballot(qm & 2), m2 = __ballot(qm & 4),
+                                             m3 = __ballot(qm & 8);
+                    n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
+                    auto put = [&](int qd, unsigned long long m, int cnt, int bit) {
+                        typedef __attribute__((address_space(3))) unsigned lds_u32w;
+                        lds_u32w *list = (lds_u32w *)(uintptr_t)(lists_base + (unsigned)qd * (kListStride * 4u));
+                        if (qm & bit)
+                            list[__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = my_slot;
+                        if (ln < kListTail) list[cnt + ln] = null_slot;
+                    };
+                    if (n0) put(0, m0, n0, 1);
+                    if (n1) put(1, m1, n1, 2);
+                    if (n2) put(2, m2, n2, 4);
+                    if (n3) put(3, m3, n3, 8);
+                    wave_sync();
+#if AMAV_ABLATE != 5 && AMAV_ABLATE != 7
+                    // this round's share of the background (see the kernel's header), from the ids already in registers
+                    for (int k = 0; k < fill_round && fill_left > 0 && fill.pos < fill.have; ++k, --fill_left)
+                        fill_tile_at<kInvDepth>(p, fill, ln);
+#endif
+                    // prefetch the next round's records while this one is blended
+                    if (!last && base + 64 + ln < n) load_records(base + 64 + ln);
+#if AMAV_ABLATE != 3 && AMAV_ABLATE != 7  /* diagnostic builds: no blending at all */
+                    if (n0 && !blend_quadrant<kInvDepth>(lists_base, (n0 + 1) >> 1, lxf0, lyf0, T0, R0, G0, B0, D0)) qalive &= ~1;
+#endif
+                }
+                if (base == 0) {  // the tile after next: its position has come back, request its queue entry
+                    i_next = __builtin_amdgcn_readfirstlane(idx2);
+                    if (i_next < total) e_after = *entry_of(i_next);
+                }
+#if AMAV_ABLATE != 3 && AMAV_ABLATE != 7
+                if (more) {
+                    if (n1 && !blend_quadrant<kInvDepth>(lists_base + kListStride * 4u, (n1 + 1) >> 1, lxf1, lyf0, T1, R1, G1, B1, D1)) qalive &= ~2;
+                }
+#endif
+                if (last) {
+                    // ---- next tile, steps 2 and 3: sort its keys into the id area (this tile has requested its last
+                    // records, and lists 0 / 1 are done with), then request the records of its first staging round
+                    if (nxt.n > 0 && nxt.n <= kPrepCap) {
+                        sort_prefetched(pk, nxt.n, L.keys, prep_cnt, order_l, ln);
+                        if (ln < nxt.n) {
+                            const float4 *g = geom_next + (size_t)order_lds[ln] * 3;
+                            g0 = g[0], g1 = g[1], g2 = g[2];
+                        }
+                        ready_next = true;
+                    } else if (nxt.n > kSortCap) {
+                        if (ln < nxt.n) {
+                            const float4 *g = geom_next + (size_t)idf * 3;
+                            g0 = g[0], g1 = g[1], g2 = g[2];
+                        }
+                        ready_next = true;
+                    }
+                }
+#if AMAV_ABLATE != 3 && AMAV_ABLATE != 7
+                if (more) {
+                    if (n2 && !blend_quadrant<kInvDepth>(lists_base + kListStride * 8u, (n2 + 1) >> 1, lxf0, lyf1, T2, R2, G2, B2, D2)) qalive &= ~4;
+                    if (n3 && !blend_quadrant<kInvDepth>(lists_base + kListStride * 12u, (n3 + 1) >> 1, lxf1, lyf1, T3, R3, G3, B3, D3)) qalive &= ~8;
+                }
+#endif
+
+                wave_sync();
+                if (last) break;
+            }
+            // the next tile's first records have had quadrants 2 and 3 to arrive.  Wait for them HERE: vector-memory operations
+            // complete in order, so behind the stores below they would only count as arrived once those have drained.
+            // (The statement redefines the registers, so the compiler attaches no wait of its own to the loads.)
+            asm volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(g0.x), "+v"(g0.y), "+v"(g0.z), "+v"(g0.w), "+v"(g1.x), "+v"(g1.y), "+v"(g1.z), "+v"(g1.w),
+                           "+v"(g2.x), "+v"(g2.y), "+v"(g2.z), "+v"(g2.w)
+                         :
+                         : "memory");
+
+            AMAV_STAMP(3);
+            // ---- write back: quadrant q of the wave = 8 rows x 128 B
+            {
+                const float Tq[4] = {fabsf(T0), fabsf(T1), fabsf(T2), fabsf(T3)};
+                const float Rq[4] = {R0, R1, R2, R3}, Gq[4] = {G0, G1, G2, G3}, Bq[4] = {B0, B1, B2, B3}, Dq[4] = {D0, D1, D2, D3};
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    const int px = X0 + 8 * (qd & 1) + lx, py = Y0 + 8 * (qd >> 1) + ly;
+                    if (px < p.W && py < p.H) {
+                        float r = Rq[qd] + Tq[qd] * p.bg[0], g = Gq[qd] + Tq[qd] * p.bg[1], bl = Bq[qd] + Tq[qd] * p.bg[2];
+                        if (p.clamp_output) {
+                            r = fminf(fmaxf(r, 0.f), 1.f);
+                            g = fminf(fmaxf(g, 0.f), 1.f);
+                            bl = fminf(fmaxf(bl, 0.f), 1.f);
+                        }
+                        const size_t pid = ((size_t)f * p.H + py) * p.W + px;
+                        reinterpret_cast<float4 *>(p.out_rgba)[pid] = make_float4(r, g, bl, 1.0f - Tq[qd]);
+                        if (kInvDepth) p.out_inv_depth[pid] = Dq[qd];
+                    }
+                }
+            }
+            AMAV_STAMP(4);
+#if AMAV_ABLATE != 5 && AMAV_ABLATE != 7
+            // what the rounds did not take (pixels finished early), and the next batch of tile ids
+            if (fill_left > 0 || fill.pos >= fill.have) fill_some<kInvDepth>(p, fill, fill_left, ln);
+            if (fill.pos >= fill.have && fill.next < fill.end) fill_fetch(p, fill, ln);
+#endif
+            if (nxt.n <= 0) break;
+            cur = nxt;
+            ready = ready_next;
+            e_next = e_after;
         }
     }
     // the rest of this wave's background tiles (all of them when it had no tile to blend; every tile of the launch
     // when the instance regions overflowed: the caller must retry)
 #if AMAV_ABLATE != 5 && AMAV_ABLATE != 7
-    for (; e0 < e1; ++e0) fill_tile<kInvDepth>(p, p.buf.empty_list[e0], lane);
+    fill_some<kInvDepth>(p, fill, 0x7fffffff, lane);
 #endif
 }
 

@@ -66,3 +66,15 @@ for lo, hi in ((1, 32), (32, 64), (64, 128), (128, 256), (256, 512), (512, 10**9
     m = (sn[:, 5] >= lo) & (sn[:, 5] < hi)
     if m.any():
         print(f"  class [{lo},{hi}): starts {np.percentile(start[m], 1):6.1f} .. {np.percentile(start[m], 99):6.1f} us (p1..p99)")
+# per work queue (= XCD): queue of a tile = (band of its tile row + frame) % 8 (bin_kernel); when does each queue's last
+# tile end, and how much tile time did it carry?
+gy = gx = 32
+idx = np.nonzero(ne)[0]
+fr, tl = idx // T, idx % T
+band = np.minimum(7, (tl // gx) * 8 // gy)
+qu = (band + fr) % 8
+for qq in range(8):
+    m = qu == qq
+    e = sn[m, 4]
+    print(f"  queue {qq}: {m.sum():6d} tiles, instances {n[ne][m].sum():8d}, tile wave-time {((sn[m, 4] - sn[m, 0]) * US).sum() / 1e3:7.2f} ms, "
+          f"last tile ends {(e.max() - t0) * US:6.1f} us, 99 % of its tiles ended by {(np.percentile(e, 99) - t0) * US:6.1f} us")
