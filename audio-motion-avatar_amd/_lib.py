@@ -55,6 +55,7 @@ class BodyTables(ctypes.Structure):
 # name -> (restype, argtypes); every symbol include/amav.h declares
 SIGNATURES = {
     "amav_version": (ctypes.c_char_p, []),
+    "amav_set_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p]),
     "amav_last_error": (ctypes.c_char_p, []),
     "amav_device_count": (ctypes.c_int, []),
     "amav_event_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p)]),

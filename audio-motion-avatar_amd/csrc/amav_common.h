@@ -36,6 +36,10 @@ inline int check_launch(const char *what) {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// amav_set_option overrides (api.hip): -1 = follow the environment variable
+int option_attn();  // 0: fp32 MFMA, 1: bf16 x 3, 2: fp16 x 2
+int option_lbs();   // 0: fp32 MFMA, 1: split
+
 // Zero `bytes` on `stream` with an ordinary kernel launch (api.hip).  Used instead of hipMemsetAsync so that a captured
 // step holds kernel nodes only (HIP-graph note).
 hipError_t zero_async(void *ptr, size_t bytes, hipStream_t stream);

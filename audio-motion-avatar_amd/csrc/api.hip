@@ -1,5 +1,7 @@
 // Library-level entry points of libamav_hip.so (version, errors, device probe) and the camera kernel.
+#include <atomic>
 #include <cstdlib>
+#include <cstring>
 
 #include "amav_common.h"
 
@@ -9,6 +11,10 @@ char *error_buffer() {
     static thread_local char buf[512] = {0};
     return buf;
 }
+
+static std::atomic<int> g_option_attn{-1}, g_option_lbs{-1};
+int option_attn() { return g_option_attn.load(std::memory_order_relaxed); }
+int option_lbs() { return g_option_lbs.load(std::memory_order_relaxed); }
 
 // 0 = zero-fill kernel (default), 1 = hipMemsetAsync (AMAV_CLEAR=memset, diagnostic only)
 static int clear_mode() {
@@ -130,4 +136,22 @@ extern "C" int amav_event_elapsed_ms(void *start, void *stop, float *ms) {
     if (rc == hipSuccess) rc = hipEventElapsedTime(ms, static_cast<hipEvent_t>(start), static_cast<hipEvent_t>(stop));
     if (rc != hipSuccess) return fail(AMAV_ERR_LAUNCH, "hipEventElapsedTime: %s", hipGetErrorString(rc));
     return AMAV_OK;
+}
+
+extern "C" int amav_set_option(const char *name, const char *value) {
+    AMAV_REQUIRE(name && value, "amav_set_option: NULL argument");
+    const bool dflt = strcmp(value, "default") == 0;
+    if (strcmp(name, "attn") == 0) {
+        const int v = dflt ? -1 : strcmp(value, "f32") == 0 ? 0 : strcmp(value, "bf16") == 0 ? 1 : strcmp(value, "fp16") == 0 ? 2 : -2;
+        AMAV_REQUIRE(v != -2, "amav_set_option: attn = \"%s\" (expected fp16, bf16, f32 or default)", value);
+        amav::g_option_attn.store(v);
+        return AMAV_OK;
+    }
+    if (strcmp(name, "lbs") == 0) {
+        const int v = dflt ? -1 : strcmp(value, "f32") == 0 ? 0 : strcmp(value, "split") == 0 ? 1 : -2;
+        AMAV_REQUIRE(v != -2, "amav_set_option: lbs = \"%s\" (expected split, f32 or default)", value);
+        amav::g_option_lbs.store(v);
+        return AMAV_OK;
+    }
+    return amav::fail(AMAV_ERR_INVALID_ARG, "amav_set_option: unknown option \"%s\"", name);
 }

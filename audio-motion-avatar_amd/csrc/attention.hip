@@ -885,6 +885,8 @@ static int attn_num_cus() {
 // AMAV_ATTN=f32 selects the fp32-MFMA kernel, AMAV_ATTN=bf16 the bf16 x 3 split kernel, anything else (default) the
 // fp16 x 2 split kernel
 static int attn_variant() {  // 0: fp32 MFMA, 1: bf16 x 3, 2: fp16 x 2
+    const int chosen = option_attn();  // amav_set_option("attn", ...)
+    if (chosen >= 0) return chosen;
     static const int v = [] {
         const char *e = getenv("AMAV_ATTN");
         if (e && strcmp(e, "f32") == 0) return 0;

@@ -629,7 +629,8 @@ static bool lbs_use_split(const amav_body_tables *t, int FT) {
         const char *e = getenv("AMAV_LBS");
         return e && strcmp(e, "f32") == 0;
     }();
-    return FT == 0 && t->blend_split != nullptr && !off;
+    const int chosen = option_lbs();  // amav_set_option("lbs", ...)
+    return FT == 0 && t->blend_split != nullptr && (chosen >= 0 ? chosen == 1 : !off);
 }
 
 static size_t lbs_ws(int F, const amav_body_tables *t, float **featT, float **A, void *ws, _Float16 **featH = nullptr,

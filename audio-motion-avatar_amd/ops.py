@@ -24,6 +24,12 @@ def tensor_version(t: torch.Tensor) -> int:
     return -1 if t.is_inference() else t._version
 
 
+def set_option(name: str, value: str):
+    """Process-wide arithmetic selection (include/amav.h, amav_set_option): attn = fp16 | bf16 | f32, lbs = split | f32,
+    value "default" = the environment's choice.  The projections' GEMM format is the host-side AMAV_GEMM variable."""
+    check(_lib.lib().amav_set_option(name.encode(), value.encode()), "amav_set_option")
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 

@@ -20,9 +20,13 @@ same workload), `parity` (GPU vs oracle on that sample; all-pixel maxima and cou
 exits non-zero after printing the line when it is false) and -- default workload at N = 1 only -- `full_path`: a few
 250-frame steps of BASELINE configs[2] (the audio-driven path the >= 30 frames/s/GPU target is quoted on) run after
 the timed region, with their own `roofline` (the self-attention kernel, HIP events around every launch),
-`cpu_baseline` and `parity` (tokens and frames after two autoregressive steps against the oracle), and `point_refiner`:
-the PTv3 point refiner the reference's default renderer runs on the same frames, with the roofline
-of its dominant kernel, the CPU oracle's time for one frame and the parity of the refined points.
+`cpu_baseline` and `parity` (tokens and frames after two autoregressive steps against the oracle);
+`full_path_exact_fp32`: the same clip with the exact-fp32 kernels selected per call (the split-product figure's
+counterpart); `point_refiner`: the PTv3 point refiner the reference's default renderer runs on the
+same frames, with the roofline of its dominant kernel, the CPU oracle's time for one frame and the parity of the
+refined points; `reference_defaults`: one 6-frame window of the reference's default renderer.yaml (upsampler + refiner +
+30 000 Gaussians) with parity of frame 0; `stress`: BASELINE configs[4] per-GPU shapes with the blend and projection
+rooflines and parity of frame 0.  Every `parity` carries an explicit `pass`; the process exits non-zero if one is false.
 """
 import argparse
 import json
@@ -110,6 +114,8 @@ def parse():
                     help="default workload only: skip the `full_path` object (a few steps of configs[2] after the timed region)")
     ap.add_argument("--no-refiner", action="store_true",
                     help="default workload only: skip the `point_refiner` object (PTv3 refiner, SURVEY 8(f) row 2)")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="default workload only: skip the `reference_defaults` and `stress` objects")
     ap.add_argument("--full-steps", type=int, default=2, help="steps (250-frame clips) of the `full_path` measurement")
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the workload timed on the CPU oracle")
     ap.add_argument("--chunks", type=int, default=1,
@@ -284,7 +290,8 @@ class FullPath:
 
     def cpu_baseline_and_parity(self, ar_steps=2):
         """Two autoregressive steps + their two rendered frames on the CPU oracle (a port), timed on this box's host
-        cores, and the HIP path's tokens / frames against them on identical inputs and weights."""
+        cores, and the HIP path's tokens / frames against them on identical inputs and weights.  The oracle's outputs
+        are kept, so a second call (the exact-fp32 kernels) compares against the same reference without re-running it."""
         from audio_motion_avatar_amd.audio_frontend import extract_audio_features
         from oracle import smplx_decoder as o_dec, transformer as o_tr
 
@@ -294,6 +301,9 @@ class FullPath:
             audio = extract_audio_features(self.waveform, 16000, self.windows * self.T, self.wav2vec).unsqueeze(0)
             got_tri, got_smpl = self.net.generate_tokens(audio, self.tri, self.smpl_tok, num_steps=ar_steps)
             got_rgba = self.render(got_tri, got_smpl)
+            if getattr(self, "_oracle", None) is not None and self._oracle[0] == ar_steps:
+                _, ref_tri, ref_smpl, img, unstable, base = self._oracle
+                return base, self._parity(ar_steps, got_tri, got_smpl, got_rgba, ref_tri, ref_smpl, img, unstable)
             p = {k: v.detach().cpu() for k, v in self.net.state_dict().items() if not k.startswith("renderer.")}
             t0 = time.perf_counter()
             ref_tri, ref_smpl = o_tr.audio_triplane_tokens(p, audio.cpu(), self.tri.cpu(), self.smpl_tok.cpu(),
@@ -306,6 +316,15 @@ class FullPath:
             t0 = time.perf_counter()
             img, alpha, unstable = oracle_render(self.renderer, self.rcfg, ref_tri, ref_params, cam)
             render_sec = (time.perf_counter() - t0) / ar_steps
+        base = {"value": 1.0 / (ar_sec + render_sec), "unit": "frames/s", "cores": cores, "kind": "port",
+                "sample": f"{ar_steps} autoregressive steps of the full-size net (8 layers, S=6304) + their {ar_steps} "
+                          f"rendered 512x512 frames through oracle/ (torch CPU, {cores} threads; C rasterizer with OpenMP): "
+                          f"{ar_sec:.2f} s per transformer step + {render_sec:.2f} s per frame for decode/LBS/raster"}
+        self._oracle = (ar_steps, ref_tri, ref_smpl, img, unstable, base)
+        return base, self._parity(ar_steps, got_tri, got_smpl, got_rgba, ref_tri, ref_smpl, img, unstable)
+
+    @staticmethod
+    def _parity(ar_steps, got_tri, got_smpl, got_rgba, ref_tri, ref_smpl, img, unstable):
         scale = float(ref_tri.abs().max())
         d_rgb = (got_rgba[..., :3].cpu() - img[0]).abs()
         parity = {"ar_steps": ar_steps, "token_scale": scale,
@@ -319,11 +338,7 @@ class FullPath:
                               and parity["rgb"]["unflagged_pixels_above_tolerance"] == 0
                               and parity["rgb"]["pixels_above_tolerance"] <= parity["rgb"]["pixels_flagged"]
                               and parity["rgb"]["max_abs_all_pixels"] <= 1.2e-2)
-        base = {"value": 1.0 / (ar_sec + render_sec), "unit": "frames/s", "cores": cores, "kind": "port",
-                "sample": f"{ar_steps} autoregressive steps of the full-size net (8 layers, S=6304) + their {ar_steps} "
-                          f"rendered 512x512 frames through oracle/ (torch CPU, {cores} threads; C rasterizer with OpenMP): "
-                          f"{ar_sec:.2f} s per transformer step + {render_sec:.2f} s per frame for decode/LBS/raster"}
-        return base, parity
+        return parity
 
 
 def pixel_report(diff, unstable, tol=1e-3):
@@ -470,6 +485,198 @@ def measure_full_path(args, device, rank, steps, warmup, with_cpu):
            "roofline": fp.attention_roofline()}
     if with_cpu:
         out["cpu_baseline"], out["parity"] = fp.cpu_baseline_and_parity()
+    return out, fp
+
+
+class exact_fp32:
+    """Context: every selectable product of the path in exact fp32 -- attention on the fp32 MFMA kernel, the LBS blend
+    product on the fp32 MFMA kernel (amav_set_option, per call) and the projections as library fp32 GEMMs (AMAV_GEMM, read
+    per call) -- instead of the default fp16 x 2 split products."""
+
+    def __enter__(self):
+        from audio_motion_avatar_amd import ops
+
+        self.saved = {k: os.environ.get(k) for k in ("AMAV_GEMM", "AMAV_SUBM")}
+        os.environ["AMAV_GEMM"] = os.environ["AMAV_SUBM"] = "f32"
+        ops.set_option("attn", "f32")
+        ops.set_option("lbs", "f32")
+
+    def __exit__(self, *exc):
+        from audio_motion_avatar_amd import ops
+
+        ops.set_option("attn", "default")
+        ops.set_option("lbs", "default")
+        for k, v in self.saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def measure_full_path_exact_fp32(fp, split_line, steps, with_cpu):
+    """The same clip, weights and process as `full_path` with the exact-fp32 kernels selected per call: the figure that
+    stands beside the split-product one (the headline's precision must be visible on the line)."""
+    with exact_fp32():
+        fp.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            rgba = fp.step()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        out = {"workload": split_line["workload"], "value": fp.F * steps / elapsed, "unit": "frames/s", "steps": steps,
+               "ms_per_step": elapsed / steps * 1e3, "ms_per_frame": elapsed / steps / fp.F * 1e3,
+               "dtype": "f32 (exact products: attention and LBS blend on v_mfma_f32_32x32x2_f32, projections as library fp32 GEMMs)",
+               "selected_by": "amav_set_option(attn=f32, lbs=f32) + AMAV_GEMM=f32, per call in this process",
+               "output_finite": bool(torch.isfinite(rgba).all()),
+               "split_product_speedup": split_line["value"] / (fp.F * steps / elapsed)}
+        if with_cpu:
+            _, out["parity"] = fp.cpu_baseline_and_parity()
+    return out
+
+
+def measure_reference_defaults(args, device, with_cpu, frames=6):
+    """The `reference_defaults` object: one window of the reference's DEFAULT renderer configuration
+    (/root/reference/src/configs/model/renderer.yaml:10-17 -- upsample_triplane: true (4 blocks, 32^2 -> 512^2), point
+    refiner on, subdivide_steps: 2 -> 30 000 Gaussians) of `frames` = T_output frames (triplane_audio_net.py:269) at
+    512 x 512 through Renderer.forward; parity of the refined points and of the frame against the CPU oracle on frame 0
+    (full-plane upsampler + PTv3 + decode + rasterizer: the windowed upsampler must agree where the points sample)."""
+    from audio_motion_avatar_amd.config import RendererConfig
+    from audio_motion_avatar_amd.renderer import Renderer
+    from audio_motion_avatar_amd.synthetic import init_random_heads, make_render_inputs
+
+    cfg = RendererConfig(image_size=(args.image, args.image), subdivide_steps=2, upsample_triplane=True,
+                         no_point_refiner=False, predict_smplx_params=False, device=device)
+    torch.manual_seed(11)
+    r = init_random_heads(Renderer(cfg).eval())
+    with torch.no_grad():
+        r.point_refiner[-1].weight.normal_(0, 0.005)  # the reference zero-initialises it (offsets == 0 until trained)
+        tokens, smpl, cam = make_render_inputs(frames, cfg, seed=42, device=device)
+        dummy = torch.zeros(1, frames, 1, 1, device=device)
+        for _ in range(2):
+            images, gauss = r(tokens, cam, dummy, smpl)
+        torch.cuda.synchronize()
+        reps = 3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            images, gauss = r(tokens, cam, dummy, smpl)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / reps * 1e3
+    plan = getattr(r, "last_window_plan", None)
+    out = {"workload": f"reference renderer.yaml defaults: TriplaneUpsampler x16 (C=256, 32^2 -> 512^2) + PTv3 point refiner "
+                       f"+ {r.num_verts} Gaussians, {frames} frames (one T_output window) at {args.image}x{args.image} through "
+                       "Renderer.forward; random weights, refiner output layer N(0, 0.005)",
+           "ms_per_window": ms, "ms_per_frame": ms / frames, "frames_per_s": frames / (ms * 1e-3),
+           "with_transformer_step_frames_per_s": None, "output_finite": bool(torch.isfinite(images).all()),
+           "coverage": float((images < 0.999).any(-1).float().mean()),
+           "upsampler_active_tiles_of_64_per_plane": [round(int(w["mask"].sum()) / frames, 1) for w in plan] if plan else None}
+    if with_cpu:
+        from oracle import lbs as o_lbs, rasterizer as o_rast, subdivide as o_sub, triplane as o_tri
+
+        cores = host_cores()
+        torch.set_num_threads(cores)
+        params = {k: v.detach().cpu() for k, v in r.state_dict().items()}
+        sp = {k: v[:, :1].cpu() for k, v in smpl.items()}
+        levels = o_sub.subdivision_levels(r.smplx_model.faces, r.smplx_model.num_verts, max(1, cfg.subdivide_steps))
+        pcfg = {k: list(getattr(cfg, k)) for k in ("enc_depths", "enc_num_head", "enc_patch_size", "dec_depths",
+                                                   "dec_num_head", "dec_patch_size")}
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            cpu_pts = o_lbs.get_smpl_vertices(r.smplx_model.oracle_arrays(torch.float32), sp, densify=(levels, r.subset_index))
+            # Stage-by-stage on identical inputs, as in the render workload's `parity`: the refiner voxelises its points
+            # (floor(100 p), point_encoder.py:33), so two LBS results 1e-6 m apart put a handful of the 30 000 points
+            # into different voxels and the network's output moves by centimetres around them
+            # (tools/debug_reference_defaults.py).  The LBS stage has its own bar; the stages behind it get the HIP
+            # path's points.
+            pts = r.get_smpl_vertices({k: v[:, :1] for k, v in smpl.items()}).cpu()
+            lbs_err = float((pts - cpu_pts).abs().max())
+            planes = o_tri.tokens_to_planes(tokens[:, :1].cpu(), cfg.triplane_resolution)
+            up = o_tri.triplane_upsampler(params, planes, cfg.num_upsample_blocks)
+            refined = o_tri.refine_points(params, up, pts, cfg.radius, pcfg)
+            g = o_tri.decode_gaussians(params, up, refined, sp["transl"].reshape(-1, 3), cfg.radius)
+            img, alpha, unstable = o_rast.render_batch(g, cam["intrinsic"][:, :1].cpu(), cam["extrinsic"][:, :1].cpu(),
+                                                       cfg.image_size, full=True)
+        cpu_s = time.perf_counter() - t0
+        got_xyz = gauss["xyz"][:1].cpu()
+        want_xyz = g["xyz"]
+        d_pts = float((got_xyz - want_xyz).abs().max())
+        d_attr = max(float((gauss[k][:1].cpu() - g[k]).abs().max()) for k in ("scale", "rot", "opacity", "color"))
+        rgb = pixel_report((images[0, :1].cpu() - img[0]).abs().amax(-1), unstable[0])
+        out["cpu_baseline"] = {"value": 1.0 / cpu_s, "unit": "frames/s", "cores": cores, "kind": "port",
+                               "sample": "frame 0 through oracle/: LBS + densify, full-plane upsampler (torch CPU convolutions), "
+                                         "PTv3 refiner, decode, C rasterizer"}
+        # the upsampled planes come from library convolutions on both sides (other kernels, other summation order: 5e-6),
+        # sampled at 512^2 and fed to 256-channel heads: measured 2e-6 m on the Gaussians' positions, 5e-5 on the others
+        out["parity"] = {"lbs_points_max_abs": lbs_err, "lbs_tolerance": 1e-5, "gaussian_xyz_max_abs_m": d_pts,
+                         "xyz_tolerance": 1e-5, "other_attributes_max_abs": d_attr, "attribute_tolerance": 2e-4,
+                         "largest_refiner_offset_m": float((refined - pts).abs().max()), "rgb": rgb, "raster_tolerance": 1e-3}
+        out["parity"]["pass"] = bool(lbs_err <= 1e-5 and d_pts <= 1e-5 and d_attr <= 2e-4 and
+                                     rgb["unflagged_pixels_above_tolerance"] == 0 and
+                                     rgb["pixels_above_tolerance"] <= rgb["pixels_flagged"] and
+                                     rgb["max_abs_all_pixels"] <= 1.2e-2)
+    return out
+
+
+def measure_stress(args, device, with_cpu, frames=32):
+    """The `stress` object: BASELINE configs[4] per-GPU shapes (triplane 128^2 x 512 channels, 50 000 Gaussians, 1024 x 1024,
+    static decode + LBS + rasterize) for `frames` frames per step, with the rooflines of the two kernels that dominate it
+    (slab projection: HBM stream; blend: HBM by bytes) and the parity of frame 0 against the CPU oracle."""
+    import dataclasses
+
+    from audio_motion_avatar_amd import ops
+    from audio_motion_avatar_amd.synthetic import make_render_inputs
+
+    sargs = argparse.Namespace(**{**vars(args), "workload": "stress", "gaussians": 50000, "image": 1024})
+    renderer, cfg = build_renderer(sargs, device)
+    F, N, H, W = frames, 50000, 1024, 1024
+    tokens, smpl, cam = make_render_inputs(F, cfg, seed=42, device=device)
+    ws = [None]
+    ev = [(ops.Event(), ops.Event())]
+    with torch.no_grad():
+        rgba, packed = renderer.render_tokens(tokens[0], smpl, cam, workspaces=ws)  # sizes the workspace
+        steps = 10
+        marks = [ops.Event() for _ in range(steps + 1)]
+        blend_ms = []
+        torch.cuda.synchronize()
+        marks[0].record()
+        for i in range(steps):
+            ops.PROFILE_EVENTS = list(ev)
+            rgba, packed = renderer.render_tokens(tokens[0], smpl, cam, workspaces=ws, check_overflow=False)
+            marks[i + 1].record()
+            torch.cuda.synchronize()
+            blend_ms.append(ev[0][0].elapsed_ms(ev[0][1]))
+        ops.PROFILE_EVENTS = None
+        assert not ws[0].status()[1], "rasterizer workspace overflowed"
+        step_ms = sorted(marks[i].elapsed_ms(marks[i + 1]) for i in range(steps))[steps // 2]
+        w_plane, _ = renderer._head_weights()
+        pe = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        for _ in range(2):
+            ops.triplane_project(tokens[0], w_plane, cfg.triplane_resolution)
+        pe[0].record()
+        for _ in range(10):
+            ops.triplane_project(tokens[0], w_plane, cfg.triplane_resolution)
+        pe[1].record()
+        torch.cuda.synchronize()
+        proj_ms = pe[0].elapsed_time(pe[1]) / 10
+    blend = sorted(blend_ms)[len(blend_ms) // 2]
+    blend_bytes = F * (16 * H * W + 40 * N)
+    slab = F * 3 * cfg.triplane_feature_dim * cfg.triplane_resolution ** 2 * 4
+    out = {"workload": f"BASELINE configs[4] per GPU: triplane 128^2 x 512 ch, 50k Gaussians, 1024x1024, {F} frames per step, "
+                       "static triplane decode + LBS + rasterize, no audio net",
+           "frames_per_s": F / (step_ms * 1e-3), "ms_per_step": step_ms, "ms_per_frame": step_ms / F,
+           "instances_per_step": int(ws[0].status()[0]),
+           "roofline_blend": {"bound": "hbm", "kernel": "render_kernel (tile blend)", "achieved": blend_bytes / (blend * 1e-3) / 1e9,
+                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": blend_bytes / (blend * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "avg_launch_ms": blend, "algorithmic_bytes_per_launch": blend_bytes, "traffic": None},
+           "roofline_project": {"bound": "hbm", "kernel": "project_kernel (triplane slab stream)",
+                                "achieved": slab / (proj_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": slab / (proj_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": proj_ms,
+                                "algorithmic_bytes_per_launch": slab, "traffic": None,
+                                "note": "timed stand-alone in this process (10 launches)"}}
+    if with_cpu:
+        base, parity = cpu_baseline_and_parity(renderer, cfg, tokens, smpl, cam, [packed, rgba], 1)
+        out["cpu_baseline"], out["parity"] = base, parity
+    del tokens, rgba, packed
     return out
 
 
@@ -785,7 +992,8 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f32 (LBS blend-shape product: fp16 x 2 split operands with fp32 accumulation, fp32-equivalent; "
+                 "everything else plain fp32)",
         "data": "synthetic",
         "step_device_ms": {"min": step_ms[0], "median": step_ms[len(step_ms) // 2], "max": step_ms[-1],
                            "note": "HIP events between consecutive steps on the compute stream (the timed region is short)"},
@@ -824,10 +1032,21 @@ def main():
         result["parity"] = parity
     if rank == 0 and world == 1 and args.workload == "render" and not args.no_full_path:
         torch.cuda.empty_cache()
-        result["full_path"] = measure_full_path(args, device, rank, args.full_steps, 1, not args.no_cpu_baseline)
+        result["full_path"], fp = measure_full_path(args, device, rank, args.full_steps, 1, not args.no_cpu_baseline)
+        result["full_path_exact_fp32"] = measure_full_path_exact_fp32(fp, result["full_path"], 1, not args.no_cpu_baseline)
+        del fp
     if rank == 0 and world == 1 and args.workload == "render" and not args.no_refiner and N == 10000:
         torch.cuda.empty_cache()
         result["point_refiner"] = measure_point_refiner(args, device, not args.no_cpu_baseline)
+    if rank == 0 and world == 1 and args.workload == "render" and not args.no_extra_configs:
+        torch.cuda.empty_cache()
+        result["reference_defaults"] = measure_reference_defaults(args, device, not args.no_cpu_baseline)
+        fpath = result.get("full_path")
+        if fpath:  # the reference's default configuration behind the audio net: one transformer step per frame
+            step_ms = fpath["roofline"]["transformer_step"]["ms"]
+            result["reference_defaults"]["with_transformer_step_frames_per_s"] = 1e3 / (result["reference_defaults"]["ms_per_frame"] + step_ms)
+        torch.cuda.empty_cache()
+        result["stress"] = measure_stress(args, device, not args.no_cpu_baseline)
     if rank == 0:
         emit(result)
     if dist is not None:

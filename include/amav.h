@@ -40,6 +40,13 @@ const char *amav_version(void);
 const char *amav_last_error(void);
 /* Number of visible HIP devices, or a negative error.  Does not create a context on a device. */
 int amav_device_count(void);
+/* Process-wide arithmetic selection, effective from the next call on (the environment variables AMAV_ATTN / AMAV_LBS give
+ * the defaults; there is no reference counterpart: the reference computes these products in library fp32).
+ *   name "attn": "fp16" (fp16 x 2 split products, default) | "bf16" (bf16 x 3) | "f32" (exact products on the fp32 MFMA)
+ *   name "lbs":  "split" (fp16 x 2 split blend product, default) | "f32" (fp32 MFMA)
+ * value "default" returns to the environment's choice.  Not to be changed while calls of that entry point are in
+ * flight on another thread (a call reads it more than once: workspace layout, then launch). */
+int amav_set_option(const char *name, const char *value);
 
 /* Timing events for callers without a HIP binding of their own (thin hipEvent wrappers; elapsed synchronises). */
 int amav_event_create(void **event);

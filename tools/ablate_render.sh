@@ -12,7 +12,7 @@ for n in 3 5 7; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC api.o /tmp/amav_ablate/rasterizer_$n.o lbs.o triplane.o attention.o frames.o splat.o cloud.o -o /tmp/amav_ablate/libamav_$n.so || exit 1
 done
 cd ../..
-B="python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-full-path --no-refiner"
+B="python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-full-path --no-refiner --no-extra-configs"
 get() { python -c "import json,sys; d=json.loads(sys.stdin.read()); print('%.4f ms blend, %.4f ms step' % (d['roofline']['avg_launch_ms'], d['step_device_ms']['median']))"; }
 {
 echo "product build:        $($B 2>/dev/null | get)"

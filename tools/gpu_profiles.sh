@@ -5,7 +5,7 @@
 #   usage (from the repo root, through gpurun): tools/gpu_profiles.sh [render|attn|refiner|all]
 what=${1:-all}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-BENCH="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-full-path --no-refiner"
+BENCH="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-full-path --no-refiner --no-extra-configs"
 pass() { # dir, seconds, rocprof args..., -- program
   d=$1; secs=$2; shift 2
   rm -rf gpurun_out/$d
