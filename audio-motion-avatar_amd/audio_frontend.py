@@ -93,9 +93,14 @@ def build_wav2vec2(model_path=None, device="cuda", seed=0):
     return model.to(device).eval()
 
 
-def _normalize(clip):
-    """Wav2Vec2FeatureExtractor(do_normalize=True): (x - mean) / sqrt(var + 1e-7) per clip."""
+def normalize_clip(clip):
+    """Wav2Vec2FeatureExtractor(do_normalize=True), the audio half of the Wav2Vec2Processor the reference calls
+    (dataset_speech_vid.py:48,88): (x - mean) / sqrt(var + 1e-7) per clip (pinned against the class itself in
+    tests/test_audio_frontend.py)."""
     return (clip - clip.mean()) / torch.sqrt(clip.var(unbiased=False) + 1e-7)
+
+
+_normalize = normalize_clip
 
 
 @torch.no_grad()

@@ -26,6 +26,7 @@ What runs where:
 """
 import math
 import os
+import warnings
 import weakref
 
 import torch
@@ -39,6 +40,10 @@ SPLIT_GEMM_MIN_ROWS = 256  # below this the operand split costs more than the fa
 SPLIT_GEMM_MAX_K = 1024    # bf16 x 3 format only: the 2048 -> 512 feed-forward output projection ran 126 + 35 (split) us
 #                            against 120 us for the tuned fp32 GEMM (6304 rows; K' = 12288 leaves ~100 output tiles)
 FP16_TARGET = 32768.0      # a tensor's bound is scaled to at most this (fp16 max 65504: 2x margin for rounding)
+# The fp16 x 2 parts keep a value exact down to 2^-17 of the scaled bound (absolute error bound * 2^-40 below that).  With
+# the largest actual value at bound * 2^-k, a 2048-term dot product stays at the fp32 level (2^-22 of its largest term)
+# while k <= 12: beyond that overshoot a block takes the bf16 x 3 format, which needs no bounds.
+FP16_MAX_OVERSHOOT = 4096.0
 
 
 _version_of = ops.tensor_version
@@ -235,7 +240,7 @@ class BasicTransformerBlock(nn.Module):
         B, S, dim = h.shape
         ff_in, ff_out = self.ff.net[0].proj, self.ff.net[2]
         pending, pending_bias = pending if pending is not None else (None, None)
-        if fp16_gemm_ok(B * S, dim):
+        if fp16_gemm_ok(B * S, dim) and self._fp16_overshoot_ok(h, pending, pending_bias, row):
             # every projection as an fp16 x 2 split GEMM: each pass writes its rows as the split operand of the GEMM that
             # follows, pre-scaled from the proven bounds of _fp16_plan, and the projections' biases are added by the
             # pass that reads their output
@@ -298,9 +303,46 @@ class BasicTransformerBlock(nn.Module):
             v_bound = v_rows * n1_l2 + (self.attn1.to_v.bias.abs().max().item() if self.attn1.to_v.bias is not None else 0.0)
             ff_bound = (h_rows * n3_l2 + h_bias) * (g_rows * n3_l2 + g_bias)
             exps = tuple(_scale_exp(b) for b in (root * w1 + b1, v_bound, root * w3 + b3, ff_bound))
+            self._fp16_bounds = (root * w1 + b1, v_bound, root * w3 + b3, ff_bound)
             return exps + ((q_rows * n1_l2, k_rows * n1_l2, v_bound),)  # attention_bias=False: no q / k bias
 
         return _memo("fp16_plan", tensors, make)
+
+    def _fp16_overshoot_ok(self, h, pending, pending_bias, row):
+        """Whether the proven bounds of _fp16_plan sit close enough to what the block actually produces for the fp16 x 2
+        parts to carry fp32 precision (FP16_MAX_OVERSHOOT).  The bounds hold for every input, but they multiply two
+        Cauchy-Schwarz bounds for the GEGLU product: LayerNorm gains of 30 and a few heavy weight rows (a trained
+        checkpoint) put them 2^20 above the activations, and everything below 2^-17 of the bound loses bits.  Measured
+        ONCE per weights version, on the first input the block sees (LayerNorm fixes the scale of what follows, so the
+        ratio barely depends on the input): one extra pass in library fp32 and one host sync."""
+        ff_in = self.ff.net[0].proj
+        tensors = (self.norm1.weight, self.norm1.bias, self.norm3.weight, self.norm3.bias, self.attn1.to_q.weight,
+                   self.attn1.to_k.weight, self.attn1.to_v.weight, ff_in.weight, ff_in.bias)
+
+        def make():
+            self._fp16_plan()
+            x = h if pending is None else h + pending + (pending_bias if pending_bias is not None else 0.0)
+            n1 = F.layer_norm(x, (x.shape[-1],), self.norm1.weight, self.norm1.bias, self.norm1.eps)
+            i = self.attn1.inner_dim
+            qkv = F.linear(n1, self.attn1._qkv_weight())
+            B, S = x.shape[:2]
+            heads = lambda t: t.reshape(B, S, self.attn1.heads, self.attn1.dim_head).transpose(1, 2)
+            a = F.scaled_dot_product_attention(heads(qkv[..., :i]), heads(qkv[..., i:2 * i]), heads(qkv[..., 2 * i:]))
+            a = a.transpose(1, 2).reshape(B, S, i)
+            x3 = x + self.attn1.to_out[0](a) + row
+            n3 = F.layer_norm(x3, (x3.shape[-1],), self.norm3.weight, self.norm3.bias, self.norm3.eps)
+            hg = F.linear(n3, ff_in.weight, ff_in.bias)
+            inner = hg.shape[-1] // 2
+            gated = hg[..., :inner] * F.gelu(hg[..., inner:])
+            actual = torch.stack([t.abs().max() for t in (n1, a, n3, gated)]).double().tolist()  # one host sync
+            self._fp16_overshoot = tuple(b / max(v, 1e-30) for b, v in zip(self._fp16_bounds, actual))
+            ok = max(self._fp16_overshoot) <= FP16_MAX_OVERSHOOT
+            if not ok:
+                warnings.warn("transformer block: the proven fp16 bounds overshoot the activations by "
+                              f"{max(self._fp16_overshoot):.3g} (> {FP16_MAX_OVERSHOOT:g}); using the bf16 x 3 format")
+            return ok
+
+        return _memo("fp16_overshoot", tensors, make)
 
     def forward(self, hidden_states, encoder_hidden_states=None):
         h = hidden_states

@@ -7,6 +7,11 @@ import numpy as np
 import torch
 
 
+def normalize_clip(clip):
+    """Wav2Vec2FeatureExtractor.zero_mean_unit_var_norm on one clip (numpy, as the processor does it)."""
+    return (clip - clip.mean()) / np.sqrt(clip.var() + 1e-7)
+
+
 def extract_audio_features(waveform, sr, frames_count, model, clip_length=8, sample_rate=16000):
     assert sr == sample_rate, "resampling (torchaudio) is not restated"
     if waveform.shape[0] > 1:
@@ -27,7 +32,7 @@ def extract_audio_features(waveform, sr, frames_count, model, clip_length=8, sam
             start_sample = max(0, waveform.shape[1] - int((end_idx - start_idx) * frame_duration * sample_rate))
             end_sample = waveform.shape[1]
         clip = waveform[:, start_sample:end_sample].numpy().squeeze()
-        clip = (clip - clip.mean()) / np.sqrt(clip.var() + 1e-7)   # Wav2Vec2FeatureExtractor.zero_mean_unit_var_norm
+        clip = normalize_clip(clip)
         with torch.no_grad():
             hidden_states = model(torch.from_numpy(clip)[None].float()).last_hidden_state
         time_steps = hidden_states.shape[1]
