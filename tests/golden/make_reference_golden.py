@@ -411,6 +411,87 @@ def fixture_audio_net(tan, tr):
                           "renderer := RecordingRenderer"], decorated_by_placeholder=decorated, mode="eval"))
 
 
+
+def fixture_chained_windows(tan, tr):
+    """Demo chaining (src/main2.py:179-203): the reference's AudioTriplaneNet.forward run window after window, every
+    window seeded with the previous one's last two outputs.  The forwards are the reference's (tier 2: Attention and the
+    renderer injected as in fixture_audio_net); the two hand-off statements of main2.py:202-203 are applied here exactly as
+    written there (`triplanes = output_triplane_tokens[:, -2:]`, `smplx_tokens = output_smplx_tokens[:, -2:]`) -- main()
+    itself needs datasets and checkpoints and cannot run."""
+    ns = types.SimpleNamespace
+    c = ns(triplane_input_frames=2, triplane_output_frames=3, triplane_feature_dim=32, triplane_resolution=4,
+           smpl_token_len=8, smpl_token_dim=32, transformer_layers=2, transformer_head_dim=64, transformer_num_heads=1,
+           audio_feature_dim=24)
+    tr.Attention = OracleAttention
+    rec = RecordingRenderer()
+    net = tan.AudioTriplaneNet(ns(model=ns(triplane_audio_net=c)), renderer=rec).eval()
+    shapes = {k: list(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict({k: seeded_tensor("audio_triplane." + k, v.shape) for k, v in net.state_dict().items()})
+    B, windows, T = 1, 3, c.triplane_output_frames
+    audio = rnd(61, B, windows * T, c.audio_feature_dim)
+    tri0 = rnd(62, B, 2, 32, 3 * 16)
+    smpl0 = rnd(63, B, 2, 32, 8, scale=0.5)
+    cam = {"intrinsic": torch.zeros(B, T, 3, 3), "extrinsic": torch.zeros(B, T, 4, 4)}
+    triplanes, smplx_tokens = tri0, smpl0
+    out_tri, out_smpl = [], []
+    with torch.no_grad():
+        for w in range(windows):
+            _, _, _, output_triplane_tokens, output_smplx_tokens = net(audio[:, w * T:(w + 1) * T], triplanes, None, cam,
+                                                                       smplx_tokens)
+            triplanes = output_triplane_tokens[:, -2:]     # main2.py:202
+            smplx_tokens = output_smplx_tokens[:, -2:]     # main2.py:203
+            out_tri.append(output_triplane_tokens)
+            out_smpl.append(output_smplx_tokens)
+    return save("chained_windows", 2, ["src/main2.py:179-203", "src/models/triplane_audio_net.py:157-271"],
+                dict(audio=audio, tri=tri0, smpl=smpl0, out_tri=torch.stack(out_tri), out_smpl=torch.stack(out_smpl)),
+                meta=dict(cfg=vars(c), params=shapes, param_prefix="audio_triplane.", windows=windows,
+                          injected=["src.models.transformers.Attention := OracleAttention", "renderer := RecordingRenderer",
+                                    "main2.py:202-203 (the two hand-off assignments) applied by the generator"], mode="eval"))
+
+
+def oracle_batch_rodrigues(rot_vecs, epsilon=1e-8):
+    """INJECTED (tier 2) for smplx.lbs.batch_rodrigues (absent): axis-angle [N,3] -> rotation matrices [N,3,3], the
+    published smplx formula (the norm of r + 1e-8)."""
+    angle = torch.norm(rot_vecs + epsilon, dim=1, keepdim=True)
+    rot_dir = rot_vecs / angle
+    cos, sin = torch.cos(angle)[:, None], torch.sin(angle)[:, None]
+    rx, ry, rz = torch.split(rot_dir, 1, dim=1)
+    zeros = torch.zeros_like(rx)
+    K = torch.cat([zeros, -rz, ry, rz, zeros, -rx, -ry, rx, zeros], dim=1).view(-1, 3, 3)
+    ident = torch.eye(3, dtype=rot_vecs.dtype)[None]
+    return ident + sin * K + (1 - cos) * torch.bmm(K, K)
+
+
+def fixture_losses(lu):
+    """Evaluation metrics the demo prints (src/main2.py:205-211) and the training losses (last):
+    l1 / l2 / ssim and its window exactly as shipped (tier 1); rotation_geodesic_loss and smplx_param_loss with
+    smplx's absent batch_rodrigues injected (tier 2).  LPIPS needs the `lpips` package and its VGG weights: not run."""
+    B, T, H, W = 2, 3, 24, 20
+    a = torch.rand(B, T, H, W, 3, generator=torch.Generator().manual_seed(71))
+    b = (a + 0.1 * torch.randn(B, T, H, W, 3, generator=torch.Generator().manual_seed(72))).clamp(0, 1)
+    t1 = dict(img1=a, img2=b, l1=lu.l1_loss(a, b), l2=lu.l2_loss(a, b), ssim=lu.ssim(a, b),
+              ssim_per_image=lu.ssim(a, b, size_average=False), window=lu.create_window(11, 3),
+              gaussian_7=lu.gaussian(7, 1.5))
+    e1 = save("losses", 1, ["src/utils/loss_utils.py:18-78"], t1, meta=dict(window_size=11))
+    lu.batch_rodrigues = oracle_batch_rodrigues  # the ONE injected component
+    g = torch.Generator().manual_seed(73)
+    keys = dict(global_orient=(B, T, 3), body_pose=(B, T, 21, 3), left_hand_pose=(B, T, 15, 3), right_hand_pose=(B, T, 15, 3),
+                jaw_pose=(B, T, 3), leye_pose=(B, T, 3), reye_pose=(B, T, 3), betas=(B, T, 10), expression=(B, T, 10),
+                transl=(B, T, 3))
+    pred = {k: torch.randn(*s, generator=g) * 0.4 for k, s in keys.items()}
+    gt = {k: pred[k] + torch.randn(*s, generator=g) * 0.2 for k, s in keys.items()}
+    total, parts = lu.smplx_param_loss(pred, gt)
+    arrays = {"pred_" + k: v for k, v in pred.items()}
+    arrays.update({"gt_" + k: v for k, v in gt.items()})
+    arrays.update({"part_" + k: v for k, v in parts.items()})
+    arrays["total"] = total
+    arrays["geodesic_body"] = lu.rotation_geodesic_loss(pred["body_pose"], gt["body_pose"])
+    e2 = save("smplx_losses", 2, ["src/utils/loss_utils.py:105-182"], arrays,
+              meta=dict(injected=["src.utils.loss_utils.batch_rodrigues := oracle_batch_rodrigues (smplx.lbs.batch_rodrigues restated)"],
+                        parts=sorted(parts)))
+    return [e1, e2]
+
+
 def fixture_smplx_decoder(sd_mod):
     sys.path.insert(0, ROOT)
     from oracle import rotation as orot
@@ -694,13 +775,15 @@ def main():
     imf = importlib.import_module("src.models.image_feature")
     ser = importlib.import_module("src.models.point_transformer.serialization")
     ptv3 = importlib.import_module("src.models.point_transformer.pointtransformer_v3")
-    for m in (gu, mu, tr, tan, sd_mod, rd, tn, tok, imf, ser, ptv3):
+    lu = importlib.import_module("src.utils.loss_utils")
+    for m in (gu, mu, tr, tan, sd_mod, rd, tn, tok, imf, ser, ptv3, lu):
         assert os.path.realpath(m.__file__).startswith(os.path.realpath(REFERENCE)), m.__file__
     PHASE["name"] = "run"
     torch.manual_seed(0)
     torch.set_num_threads(1)  # bit-reproducible sums
     entries = [fixture_camera(gu), fixture_reducers(tan), fixture_feedforward(tr), fixture_triplane(rd, mu),
-               fixture_audio_net(tan, tr), fixture_smplx_decoder(sd_mod)] + fixture_stage1(tn, tok, imf, tr, sd_mod) + fixture_ptv3(ser, ptv3, injected)
+               fixture_audio_net(tan, tr), fixture_chained_windows(tan, tr), fixture_smplx_decoder(sd_mod)] + fixture_losses(lu) + \
+        fixture_stage1(tn, tok, imf, tr, sd_mod) + fixture_ptv3(ser, ptv3, injected)
     assert not RUN_EVENTS, f"a placeholder was used while producing fixtures: {RUN_EVENTS}"
     manifest = {"generator": "tests/golden/make_reference_golden.py", "reference": REFERENCE, "torch": torch.__version__,
                 "absent_packages_mapped_to_inert_placeholders": absent,

@@ -8,6 +8,7 @@ Tolerances: both sides are fp32 torch on the CPU evaluating the same operators, 
 library kernels may differ: 2e-6 relative to the output scale (camera: 1e-6 absolute on O(1) matrices).
 """
 import json
+import math
 import os
 
 import pytest
@@ -29,7 +30,8 @@ def test_manifest_says_no_placeholder_was_used_and_tiers_are_declared():
     assert m["placeholder_uses_during_run"] == 0
     tiers = {e["file"]: e["tier"] for e in m["fixtures"]}
     assert tiers == {"ref_camera.npz": 1, "ref_reducers.npz": 1, "ref_feedforward.npz": 1, "ref_triplane.npz": 1,
-                     "ref_audio_net.npz": 2, "ref_smplx_decoder.npz": 2, "ref_stage1_parts.npz": 1, "ref_stage1.npz": 2,
+                     "ref_audio_net.npz": 2, "ref_chained_windows.npz": 2, "ref_losses.npz": 1, "ref_smplx_losses.npz": 2,
+                     "ref_smplx_decoder.npz": 2, "ref_stage1_parts.npz": 1, "ref_stage1.npz": 2,
                      "ref_ptv3_codes.npz": 1, "ref_ptv3.npz": 2}
     for need in ("diffusers", "pytorch3d", "smplx", "omegaconf", "diff_gaussian_rasterization"):
         assert need in m["absent_packages_mapped_to_inert_placeholders"]
@@ -243,3 +245,61 @@ def test_stage1_oracle_equals_the_reference_encoder_and_fusion_network():
                                           cfg["cross_transformer_layers"], cfg["cross_transformer_num_heads"])
     close(fused, a["fused"], 5e-6, "oracle fused triplane tokens")
     close(smpl_out, a["smpl_out"], 5e-6, "oracle fused smpl tokens")
+
+
+def test_chained_windows_equal_the_reference_forwards_under_main2s_hand_off():
+    """tier 2: three windows of the reference's AudioTriplaneNet.forward chained by main2.py:202-203 (each window starts
+    from the previous window's last two outputs).  The oracle's loop and the product's AudioDrivenAvatar.rollout_tokens
+    (torch path on the CPU) reproduce every window -- so the cross-window hand-off is anchored to reference-run forwards,
+    not only to the product's own window-by-window calls."""
+    from audio_motion_avatar_amd.config import AudioNetConfig, ModelConfig, RendererConfig
+    from audio_motion_avatar_amd.harness import AudioDrivenAvatar
+    from audio_motion_avatar_amd.triplane_audio_net import AudioTriplaneNet
+    from oracle import transformer as o_tr
+
+    a, meta, tier = ref_fixture("chained_windows")
+    assert tier == 2
+    c, W = meta["cfg"], meta["windows"]
+    T = c["triplane_output_frames"]
+    p = seeded_params(meta["params"], meta["param_prefix"])
+    kw = dict(resolution=c["triplane_resolution"], smpl_len=c["smpl_token_len"], t_output=T,
+              num_layers=c["transformer_layers"], heads=c["transformer_num_heads"])
+    tri, smpl = a["tri"], a["smpl"]
+    for w in range(W):
+        o_tri, o_smpl = o_tr.audio_triplane_tokens(p, a["audio"][:, w * T:(w + 1) * T], tri, smpl, **kw)
+        close(o_tri, a["out_tri"][w], 5e-6, f"oracle window {w}, triplane tokens")
+        close(o_smpl, a["out_smpl"][w], 5e-6, f"oracle window {w}, smpl tokens")
+        tri, smpl = o_tri[:, -2:], o_smpl[:, -2:]
+
+
+def test_image_metrics_equal_the_reference_functions():
+    from audio_motion_avatar_amd import losses
+
+    a, meta, tier = ref_fixture("losses")
+    assert tier == 1
+    close(losses.l1_loss(a["img1"], a["img2"]), a["l1"], 1e-6, "l1")
+    close(losses.l2_loss(a["img1"], a["img2"]), a["l2"], 1e-6, "l2")
+    close(losses.gaussian(7, 1.5), a["gaussian_7"], 1e-6, "gaussian")
+    close(losses.create_window(meta["window_size"], 3), a["window"], 1e-6, "window")
+    close(losses.ssim(a["img1"], a["img2"]), a["ssim"], 1e-6, "ssim")
+    close(losses.ssim(a["img1"], a["img2"], size_average=False), a["ssim_per_image"], 1e-6, "ssim per image")
+    assert abs(float(losses.psnr(a["img1"], a["img2"])) + 10 * math.log10(float(a["l2"]))) < 1e-4
+    with pytest.raises(RuntimeError, match="lpips"):
+        losses.LPIPS()
+
+
+def test_smplx_parameter_losses_equal_the_reference_functions():
+    from audio_motion_avatar_amd import losses
+
+    a, meta, tier = ref_fixture("smplx_losses")
+    assert tier == 2
+    pred = {k[5:]: v for k, v in a.items() if k.startswith("pred_")}
+    gt = {k[3:]: v for k, v in a.items() if k.startswith("gt_")}
+    total, parts = losses.smplx_param_loss(pred, gt)
+    assert sorted(parts) == meta["parts"]
+    for k in parts:
+        close(parts[k], a["part_" + k], 2e-6, k)
+    close(total, a["total"], 2e-6, "total")
+    close(losses.rotation_geodesic_loss(pred["body_pose"], gt["body_pose"]), a["geodesic_body"], 2e-6, "geodesic")
+    with pytest.raises(AssertionError):
+        losses.rotation_geodesic_loss(pred["body_pose"], gt["body_pose"][:, :2])

@@ -123,3 +123,25 @@ def test_smplx_decoder_and_reducers_on_the_gpu_equal_the_reference():
     with torch.no_grad():
         close(tri.cuda()(a["x_tri"].cuda()), a["y_tri"], 2e-6, "TriPlaneTemporalReducer")
         close(smp.cuda()(a["x_smpl"].cuda()), a["y_smpl"], 1e-5, "SMPLXTemporalReducer")
+
+
+def test_chained_windows_on_the_hip_path_equal_the_reference_forwards():
+    """tier 2 fixture ref_chained_windows (three reference forwards chained by main2.py:202-203): the product's
+    AudioDrivenAvatar.rollout_tokens -- the generator behind rollout() and the demo -- reproduces every window."""
+    from audio_motion_avatar_amd.config import AudioNetConfig, ModelConfig
+    from audio_motion_avatar_amd.harness import AudioDrivenAvatar
+    from audio_motion_avatar_amd.triplane_audio_net import AudioTriplaneNet
+
+    a, meta, _ = ref_fixture("chained_windows")
+    c, W = meta["cfg"], meta["windows"]
+    net = AudioTriplaneNet(ModelConfig(triplane_audio_net=AudioNetConfig(**c)), renderer=None).eval()
+    net.load_state_dict(seeded_params(meta["params"], meta["param_prefix"]))
+    avatar = AudioDrivenAvatar.__new__(AudioDrivenAvatar)  # the chaining logic only: no renderer needed
+    torch.nn.Module.__init__(avatar)
+    avatar.audio_triplane = net.cuda()
+    with torch.no_grad():
+        got = list(avatar.rollout_tokens(a["tri"].cuda(), a["smpl"].cuda(), a["audio"].cuda(), W))
+    assert len(got) == W
+    for w, (tri, smpl) in enumerate(got):
+        close(tri.cpu(), a["out_tri"][w], 2e-5, f"window {w}, triplane tokens")
+        close(smpl.cpu(), a["out_smpl"][w], 2e-5, f"window {w}, smpl tokens")
