@@ -39,6 +39,7 @@ class RasterArgs(ctypes.Structure):
         ("instance_capacity", ctypes.c_int64),
         ("profile_start_event", ctypes.c_void_p), ("profile_stop_event", ctypes.c_void_p),
         ("debug_stamps", ctypes.c_void_p),
+        ("wire", ctypes.c_void_p), ("wire_bytes", ctypes.c_size_t), ("wire_capacity_tiles", ctypes.c_int64),
     ]
 
 

@@ -36,6 +36,13 @@ inline int check_launch(const char *what) {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Tile-sparse wire format of the frame exchange (frames.hip has the description): shared with the rasterizer, which can
+// emit it directly (amav_raster_args.wire)
+constexpr int kWireHeaderInts = 16;
+constexpr int kWireMagic = 0x414d4156;  // "AMAV"
+constexpr int kWireTileBytes = 16 * 16 * 3;
+inline size_t wire_payload_at(int F, int tiles) { return ((size_t)(kWireHeaderInts + F + tiles) * 4 + 15) / 16 * 16; }
+
 // amav_set_option overrides (api.hip): -1 = follow the environment variable
 int option_attn();  // 0: fp32 MFMA, 1: bf16 x 3, 2: fp16 x 2
 int option_lbs();   // 0: fp32 MFMA, 1: split

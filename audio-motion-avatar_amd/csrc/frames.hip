@@ -32,14 +32,13 @@ __global__ __launch_bounds__(256) void rgba_to_rgb8_kernel(size_t quads, const f
 // Tile-sparse wire format of the exchange (lossless).  A rendered avatar frame is mostly background: only the 16x16
 // tiles that differ from the background colour travel, so the all-gather moves ~1/5 of the bytes of dense uint8 RGB.
 //   wire = header (16 int32: magic, count, cap, F, T, H, W, bg) | stored tiles per frame int32[F] | offsets int32[F*T]
-//          (-1 = background tile, else the tile's slot in the payload) | payload [cap][16*16*3] uint8, tiles in
-//          (frame, tile) order
+//          (-1 = background tile, else the tile's slot in the payload) | payload [cap][16*16*3] uint8 (pack stores
+//          the tiles in (frame, tile) order; readers go through `offsets`, so any assignment of slots is valid --
+//          the rasterizer's direct emission hands out slots frame by frame in completion order)
 // pack  : flags -> exclusive scan -> compaction (three launches, no host sync); tiles past `cap` are dropped and
 //         `count` > `cap` tells every receiver (unpack raises its overflow flag; the caller re-packs with more room).
 // unpack: every tile of every gathered buffer is written back into dense [frames, H, W, 3] uint8.
-constexpr int kWireHeaderInts = 16;
-constexpr int kWireMagic = 0x414d4156;  // "AMAV"
-constexpr int kTileBytes = 16 * 16 * 3;
+constexpr int kTileBytes = kWireTileBytes;  // header constants: amav_common.h
 
 __device__ __forceinline__ unsigned char quant8(float v) { return (unsigned char)(fminf(fmaxf(v, 0.f), 1.f) * 255.0f); }
 
@@ -349,7 +348,6 @@ __global__ __launch_bounds__(kDeltaWaves * 64) void tile_unpack_delta_kernel(int
     }
 }
 
-static size_t wire_payload_at(int F, int tiles) { return ((size_t)(kWireHeaderInts + F + tiles) * 4 + 15) / 16 * 16; }
 
 }  // namespace amav
 

@@ -28,6 +28,7 @@
 //                  full 128-byte lines.  Tiles reach the waves through eight work queues (one per XCD: tile-row
 //                  bands, rotating with the frame) bucketed by list length and dispatched longest first.
 #include <algorithm>
+#include <cmath>
 #include <cstddef>
 #include <cstdlib>
 
@@ -113,6 +114,11 @@ struct Params {
     long long cap_per_frame;
     int qcap;  // entries per work queue
     unsigned long long *stamps;  // diagnostic: [F*T][6] s_memtime stamps per tile wave, or NULL
+    // direct emission of the exchange's wire format (amav_raster_args.wire), or wire_header == NULL
+    int *wire_header, *wire_frame_counts, *wire_offsets;
+    unsigned char *wire_payload;
+    int wire_cap;
+    unsigned wire_bg;
     Buffers buf;
 };
 
@@ -319,7 +325,7 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int *lds_wave, int *t
     return wave_prefix + incl - v;
 }
 
-// grid = F blocks of 1024 threads; dynamic LDS = (2*T + 16 + 3*8*(kBuckets+1)) ints: counts[T], cursor[T], scratch, classes
+// grid = F blocks of 1024 threads; dynamic LDS = (2*T + 48 + 3*8*(kBuckets+1)) ints: counts[T], cursor[T], classes, scratch[48]
 template <bool kPacked>
 __global__ __launch_bounds__(1024) void bin_kernel(Params p) {
     extern __shared__ int bin_lds[];
@@ -378,6 +384,28 @@ __global__ __launch_bounds__(1024) void bin_kernel(Params p) {
         }
     }
     const bool fits = (long long)total <= p.cap_per_frame;
+    // slots of this frame's non-empty tiles in the wire buffer's payload: in tile order inside the frame, the frame's
+    // range reserved with one atomic on the wire header's count (frames land in completion order; readers go through
+    // the offsets table, so the order is immaterial)
+    int wire_slot = 0;
+    if (p.wire_header) {
+        int mine = 0;
+        for (int k = 0; k < per; ++k)
+            if (t0 + k < p.T && fits && counts[t0 + k] > 0) ++mine;
+        int frame_tiles;
+        const int before = block_exclusive_scan(mine, scratch, &frame_tiles);
+        if (threadIdx.x == 0) {
+            scratch[32] = atomicAdd(&p.wire_header[1], frame_tiles);
+            p.wire_frame_counts[f] = frame_tiles;
+            if (f == 0) {
+                p.wire_header[0] = kWireMagic, p.wire_header[2] = p.wire_cap, p.wire_header[3] = p.F;
+                p.wire_header[4] = p.T, p.wire_header[5] = p.H, p.wire_header[6] = p.W, p.wire_header[7] = (int)p.wire_bg;
+            }
+        }
+        __syncthreads();
+        wire_slot = scratch[32] + before;
+        __syncthreads();
+    }
     // work items of the blend kernel: non-empty tiles into the work queues, bucketed by list length; empty tiles into
     // the fill list.  Queue of a tile = (band of its tile row + frame) % 8: every queue (= XCD, see render_kernel)
     // gets one eighth of EVERY frame, rotating, so the queues carry equal work whatever the frames look like, and a
@@ -406,10 +434,12 @@ __global__ __launch_bounds__(1024) void bin_kernel(Params p) {
             const int kind = c == 0 ? kBuckets : bucket_of(c);
             const int qi = queue_of(t0 + k), slot = qi * kCls + kind;
             const int pos = cls[kQK + slot] + atomicAdd(&cls[2 * kQK + slot], 1);
+            if (p.wire_header) p.wire_offsets[(size_t)f * p.T + t0 + k] = kind == kBuckets ? -1 : wire_slot;
             if (kind == kBuckets)
                 p.buf.empty_list[pos] = f * p.T + t0 + k;
             else
-                p.buf.queue[((size_t)qi * kBuckets + kind) * p.qcap + pos] = make_int4(f * p.T + t0 + k, cursor[t0 + k], c, 0);
+                p.buf.queue[((size_t)qi * kBuckets + kind) * p.qcap + pos] =
+                    make_int4(f * p.T + t0 + k, cursor[t0 + k], c, p.wire_header ? wire_slot++ : 0);
         }
     if (threadIdx.x == 0) {
         off[p.T] = total;
@@ -1019,6 +1049,7 @@ __device__ __forceinline__ void fill_tile_at(const Params &p, FillCursor &c, int
 // ---- tile preparation under the previous tile
 struct TileRef {
     int item, beg, n;  // frame * T + tile, list offset inside the frame's key region, list length (all wave-uniform)
+    int slot;          // the tile's slot in the wire buffer's payload (direct emission of the exchange format)
 };
 
 constexpr int kPrepCap = 256;   // lists up to this length are sorted while the previous tile is still blending
@@ -1211,7 +1242,7 @@ __global__ __launch_bounds__(64, kRenderWavesPerSimd) void render_kernel(Params 
         if (lane == 0) idx_v = stride + atomicAdd(next, 1);
         const int4 e0 = *entry_of(i_cur);
         TileRef cur = {__builtin_amdgcn_readfirstlane(e0.x), __builtin_amdgcn_readfirstlane(e0.y),
-                       __builtin_amdgcn_readfirstlane(e0.z)};
+                       __builtin_amdgcn_readfirstlane(e0.z), __builtin_amdgcn_readfirstlane(e0.w)};
         bool ready = false;  // cur's blend order is in LDS and its first records are on their way
         float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0, g2 = g0;
         int i_next = __builtin_amdgcn_readfirstlane(idx_v);
@@ -1295,7 +1326,7 @@ __global__ __launch_bounds__(64, kRenderWavesPerSimd) void render_kernel(Params 
             const float X0f = (float)X0, Y0f = (float)Y0;
 
             // the next tile (filled in at the start of the last round)
-            TileRef nxt = {0, 0, 0};
+            TileRef nxt = {0, 0, 0, 0};
             bool ready_next = false;
             const float4 *geom_next = geom;
 
@@ -1317,6 +1348,7 @@ __global__ __launch_bounds__(64, kRenderWavesPerSimd) void render_kernel(Params 
                     nxt.item = __builtin_amdgcn_readfirstlane(e_next.x);
                     nxt.beg = __builtin_amdgcn_readfirstlane(e_next.y);
                     nxt.n = __builtin_amdgcn_readfirstlane(e_next.z);
+                    nxt.slot = __builtin_amdgcn_readfirstlane(e_next.w);
                     if (nxt.n > 0) {
                         const int fn = nxt.item / p.T;
                         geom_next = p.buf.geom + (size_t)fn * p.N * 3;
@@ -1442,6 +1474,32 @@ __global__ __launch_bounds__(64, kRenderWavesPerSimd) void render_kernel(Params 
                         if (kInvDepth) p.out_inv_depth[pid] = Dq[qd];
                     }
                 }
+                // ---- the exchange's wire format, straight from the registers: the tile as 16 x 16 x 3 bytes in row
+                // order (what amav_frames_pack_tiles would quantise out of the fp32 frame).  The lanes hold one pixel
+                // per quadrant; the staging area (idle now) turns that into 12 contiguous bytes per lane.
+                if (p.wire_header && cur.slot < p.wire_cap) {
+                    unsigned char *bytes = reinterpret_cast<unsigned char *>(L.geo);
+                    const unsigned bgw = p.wire_bg;
+#pragma unroll
+                    for (int qd = 0; qd < 4; ++qd) {
+                        const int tx16 = 8 * (qd & 1) + lx, ty16 = 8 * (qd >> 1) + ly;
+                        unsigned cr = bgw & 255u, cg = (bgw >> 8) & 255u, cb = (bgw >> 16) & 255u;  // outside the image
+                        if (X0 + tx16 < p.W && Y0 + ty16 < p.H) {
+                            const float r = Rq[qd] + Tq[qd] * p.bg[0], g = Gq[qd] + Tq[qd] * p.bg[1], bl = Bq[qd] + Tq[qd] * p.bg[2];
+                            cr = (unsigned)(unsigned char)(fminf(fmaxf(r, 0.f), 1.f) * 255.0f);
+                            cg = (unsigned)(unsigned char)(fminf(fmaxf(g, 0.f), 1.f) * 255.0f);
+                            cb = (unsigned)(unsigned char)(fminf(fmaxf(bl, 0.f), 1.f) * 255.0f);
+                        }
+                        unsigned char *px3 = bytes + (ty16 * 16 + tx16) * 3;
+                        px3[0] = (unsigned char)cr, px3[1] = (unsigned char)cg, px3[2] = (unsigned char)cb;
+                    }
+                    wave_sync();
+                    const unsigned *words = reinterpret_cast<const unsigned *>(bytes) + ln * 3;
+                    const unsigned w0 = words[0], w1 = words[1], w2 = words[2];
+                    unsigned *dst = reinterpret_cast<unsigned *>(p.wire_payload + (size_t)cur.slot * kWireTileBytes) + ln * 3;
+                    dst[0] = w0, dst[1] = w1, dst[2] = w2;
+                    wave_sync();  // the staging area is the next tile's again
+                }
             }
             AMAV_STAMP(4);
 #if AMAV_ABLATE != 5 && AMAV_ABLATE != 7
@@ -1515,7 +1573,7 @@ extern "C" int amav_rasterize_forward(const amav_raster_args *a, void *stream_) 
     AMAV_REQUIRE(gx < 65536 && gy < 65536, "amav_rasterize_forward: image too large");
     const int T = gx * gy;
     AMAV_REQUIRE((long long)F * T < (1ll << 31), "amav_rasterize_forward: F * tiles overflows int32");
-    const size_t bin_lds = ((size_t)2 * T + 16 + 3 * kQueues * (kBuckets + 1)) * sizeof(int);
+    const size_t bin_lds = ((size_t)2 * T + 48 + 3 * kQueues * (kBuckets + 1)) * sizeof(int);
     AMAV_REQUIRE(bin_lds <= 160 * 1024, "amav_rasterize_forward: %d tiles need %zu B of LDS in the binning block (max 160 KiB)",
                  T, bin_lds);
     const long long cap_per_frame = a->instance_capacity / F;
@@ -1538,6 +1596,25 @@ extern "C" int amav_rasterize_forward(const amav_raster_args *a, void *stream_) 
     p.cap_per_frame = cap_per_frame;
     p.qcap = (int)queue_capacity(F, gx, gy);
     p.stamps = static_cast<unsigned long long *>(a->debug_stamps);
+    p.wire_header = nullptr, p.wire_frame_counts = nullptr, p.wire_offsets = nullptr, p.wire_payload = nullptr;
+    p.wire_cap = 0, p.wire_bg = 0;
+    if (a->wire) {
+        AMAV_REQUIRE(a->clamp_output, "amav_rasterize_forward: the wire output carries the clamped colours (set clamp_output)");
+        AMAV_REQUIRE((reinterpret_cast<uintptr_t>(a->wire) & 15) == 0 && a->wire_capacity_tiles >= 0 &&
+                         a->wire_capacity_tiles <= (long long)F * T,
+                     "amav_rasterize_forward: bad wire buffer (alignment, or capacity %lld outside [0, %lld])",
+                     (long long)a->wire_capacity_tiles, (long long)F * T);
+        const size_t wire_need = (wire_payload_at(F, F * T) + (size_t)a->wire_capacity_tiles * kWireTileBytes + 15) / 16 * 16;
+        if (a->wire_bytes < wire_need)
+            return fail(AMAV_ERR_WORKSPACE, "amav_rasterize_forward: wire buffer %zu < required %zu", a->wire_bytes, wire_need);
+        p.wire_header = static_cast<int *>(a->wire);
+        p.wire_frame_counts = p.wire_header + kWireHeaderInts;
+        p.wire_offsets = p.wire_frame_counts + F;
+        p.wire_payload = static_cast<unsigned char *>(a->wire) + wire_payload_at(F, F * T);
+        p.wire_cap = (int)a->wire_capacity_tiles;
+        auto q8 = [](float v) { return (unsigned)(unsigned char)(std::fmin(std::fmax(v, 0.f), 1.f) * 255.0f); };
+        p.wire_bg = q8(a->bg[0]) | (q8(a->bg[1]) << 8) | (q8(a->bg[2]) << 16);
+    }
 
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     static const hipError_t attr[2] = {
@@ -1559,6 +1636,8 @@ extern "C" int amav_rasterize_forward(const amav_raster_args *a, void *stream_) 
                         a->colors.frame_stride == a->means3d.frame_stride;
     if (zero_async(p.buf.status, sizeof(Status), stream) != hipSuccess)
         return fail(AMAV_ERR_LAUNCH, "amav_rasterize_forward: status clear failed");
+    if (p.wire_header && zero_async(p.wire_header, (size_t)kWireHeaderInts * 4, stream) != hipSuccess)
+        return fail(AMAV_ERR_LAUNCH, "amav_rasterize_forward: wire header clear failed");
 
     if (packed)
         bin_kernel<true><<<F, 1024, bin_lds, stream>>>(p);

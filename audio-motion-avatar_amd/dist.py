@@ -105,6 +105,8 @@ class FrameAllGather:
         self.full = [torch.empty(world_size * frames, height, width, 3, dtype=torch.uint8, device=device)
                      for _ in range(2)]
         self.turn = 0
+        self._done = [torch.cuda.Event() for _ in range(2)]  # side stream has finished sending local[i]
+        self._sent = [False, False]
         if wire == "dense":
             self.local = [torch.empty(frames, height, width, 3, dtype=torch.uint8, device=device) for _ in range(2)]
         else:
@@ -169,11 +171,12 @@ class FrameAllGather:
             req.wait()  # RCCL: orders the current stream after the transfers (no host block); gloo: blocks
 
     # ---- one step ------------------------------------------------------------------------------------------------------
-    def submit(self, rgba: torch.Tensor, tile_hint=None) -> torch.Tensor:
+    def submit(self, rgba: torch.Tensor, tile_hint=None, packed=False) -> torch.Tensor:
         """rgba: contiguous fp32 [..., H, W, 4] produced on the current stream.  Returns the (future) full sequence
         [world * F, H, W, 3] uint8; call wait() before reading it on the current stream.  `tile_hint` (sparse wire):
         int32 [F * tiles], zero where the tile is known to be background (RasterWorkspace.tile_counts()), which saves
-        one pass over the fp32 frames."""
+        one pass over the fp32 frames.  `packed`: the rasterizer has already written wire_target() on the current
+        stream: no pack pass at all."""
         from . import ops
 
         if self.wire == "sparse" and self.capacity is None:
@@ -190,12 +193,25 @@ class FrameAllGather:
                 ops.frames_to_rgb8(rgba.view(F, H, W, 4), out=self.local[i])
                 self._gather(self.full[i].view(self.world, F, H, W, 3), self.local[i])
             else:
-                ops.frames_pack_tiles(rgba.view(F, H, W, 4), self.capacity, self.bg, wire=self.local[i],
-                                      tile_hint=tile_hint)
+                if not packed:
+                    ops.frames_pack_tiles(rgba.view(F, H, W, 4), self.capacity, self.bg, wire=self.local[i],
+                                          tile_hint=tile_hint)
                 self._gather(self.gathered[i], self.local[i])
                 ops.frames_unpack_tiles(self.gathered[i], self.world, F, H, W, self.capacity, out=self.full[i],
                                         status=self.status, state=self.tile_state[i])
+                self._done[i].record(self.stream)
+                self._sent[i] = True
         return self.full[i]
+
+    def wire_target(self):
+        """(buffer, capacity) of the wire buffer the NEXT submit() will send: hand it to the rasterizer
+        (Renderer.render_tokens(wire=...) / ops.rasterize(wire=...)), which then writes the exchange format itself, and
+        call submit(rgba, packed=True) -- the pack pass over the fp32 frames disappears.  Sparse wire, after calibrate()."""
+        if self.wire != "sparse" or self.capacity is None:
+            raise RuntimeError("wire_target(): sparse wire only, after calibrate()")
+        if self._sent[self.turn]:  # the exchange that last used this buffer (two steps ago) must have finished with it
+            torch.cuda.current_stream().wait_event(self._done[self.turn])
+        return self.local[self.turn], self.capacity
 
     def wait(self):
         torch.cuda.current_stream().wait_stream(self.stream)

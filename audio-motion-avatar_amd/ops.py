@@ -152,12 +152,15 @@ def default_instance_capacity(num_frames, num_gaussians, per_gaussian=16):
 def rasterize(means3d, rotations, scales, opacities, colors, viewmatrix, projmatrix, tanfov, height, width,
               bg=(1.0, 1.0, 1.0), apply_activations=False, scale_modifier=1.0, antialiasing=False, clamp_output=False,
               want_inv_depth=False, want_radii=False, workspace=None, check_overflow=True, out_rgba=None,
-              profile_events=None):
+              profile_events=None, wire=None):
     """Batched tile rasterizer.  Gaussian attributes are [F,N,*] (frame stride 0 = shared across frames).
 
     Returns dict(rgba [F,H,W,4], inv_depth [F,H,W] | None, radii [F,N] | None, workspace).
     With check_overflow the call synchronises once to read the instance count and transparently retries with a
     larger workspace; without it the caller must consult workspace.status() before trusting the output.
+    `wire`: (uint8 buffer, capacity in tiles) -- the rasterizer also writes the frame exchange's tile-sparse wire buffer
+    (include/amav.h, amav_raster_args.wire; needs clamp_output): what frames_pack_tiles would produce from these frames
+    with the tile counts as hint, without the extra pass.
     """
     a_m, means3d = _attr(means3d, "means3d", 3)
     a_r, rotations = _attr(rotations, "rotations", 4)
@@ -204,6 +207,11 @@ def rasterize(means3d, rotations, scales, opacities, colors, viewmatrix, projmat
         args.instance_capacity = ws.capacity
         if DEBUG_STAMPS is not None:
             args.debug_stamps = DEBUG_STAMPS.data_ptr()
+        if wire is not None:
+            buf, cap = wire
+            if buf.dtype != torch.uint8 or not buf.is_cuda or not buf.is_contiguous():
+                raise AmavError("rasterize: wire must be a contiguous uint8 device buffer")
+            args.wire, args.wire_bytes, args.wire_capacity_tiles = buf.data_ptr(), buf.numel(), int(cap)
         ev = profile_events
         if ev is None and PROFILE_EVENTS:
             ev = PROFILE_EVENTS.pop(0)

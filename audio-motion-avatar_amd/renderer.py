@@ -215,7 +215,7 @@ class Renderer(nn.Module):
         return packed if side_work is None else (packed, side_result)
 
     def render_tokens(self, triplane_tokens, smpl_params, cam_params, chunks=1, workspaces=None, check_overflow=True,
-                      bg_color=None, window_plan=None):
+                      bg_color=None, window_plan=None, wire=None):
         """tokens [F,C,3R^2] + SMPL-X params [B,T,...] (B*T = F) + cameras -> (rgba [F,H,W,4], packed [F,N,16]).
 
         The body of forward() after the SMPL-X decoder.  With `chunks` > 1 the frames are split into that many
@@ -224,6 +224,8 @@ class Renderer(nn.Module):
         `workspaces`: optional list of per-chunk RasterWorkspace objects (reused across calls; resized entries are
         written back).  With check_overflow=False the caller must check workspaces[i].status() itself.
         `window_plan`: see gaussians_from_tokens (covers all F frames; every frame group checks its own slice of it).
+        `wire`: (uint8 buffer, capacity in tiles) -- the rasterizer writes the exchange's wire buffer of these F frames
+        itself (ops.rasterize; dist.FrameAllGather.wire_target()); one frame group only.
         """
         F = triplane_tokens.shape[0]
         H, W = int(self.cfg.image_size[0]), int(self.cfg.image_size[1])
@@ -231,6 +233,8 @@ class Renderer(nn.Module):
         K = cam_params["intrinsic"].reshape(F, 3, 3)
         E = cam_params["extrinsic"].reshape(F, 4, 4)
         chunks = max(1, min(int(chunks), F))
+        if wire is not None and chunks != 1:
+            raise AmavError("render_tokens: the wire buffer covers the whole shard; use chunks=1 with it")
         bounds = [(F * i // chunks, F * (i + 1) // chunks) for i in range(chunks)]
         dev = triplane_tokens.device
         rgba = torch.empty(F, H, W, 4, device=dev)
@@ -259,7 +263,7 @@ class Renderer(nn.Module):
                     g = self.unpack_gaussians(packed)
                     out = render_batch(g, K[s:e].unsqueeze(0), E[s:e].unsqueeze(0), self.cfg, bg_color,
                                        workspace=workspaces[ci], check_overflow=check_overflow, out_rgba=rgba[s:e],
-                                       return_workspace=True, camera=camera[:3])
+                                       return_workspace=True, camera=camera[:3], wire=wire)
                     workspaces[ci] = out[1]
         finally:  # also on _WindowTooSmall from a later frame group: the side streams' work is joined before a re-render
             for st in used:
@@ -662,7 +666,7 @@ def render_multi_view(gaussians, K, E, args, bg_color=None, debug=False):
 
 
 def render_batch(gaussians, K, E, args, bg_color=None, debug=False, return_alpha=False, workspace=None,
-                 check_overflow=True, return_rgba=False, out_rgba=None, return_workspace=False, camera=None):
+                 check_overflow=True, return_rgba=False, out_rgba=None, return_workspace=False, camera=None, wire=None):
     """renderer.py:447-479: gaussians dict [(B*T),N,*], K [B,T,3,3], E [B,T,4,4] -> images [B,T,H,W,3] in [0,1].
 
     One camera launch + one rasterizer launch sequence for all B*T frames.  The returned image is a view of the
@@ -690,7 +694,7 @@ def render_batch(gaussians, K, E, args, bg_color=None, debug=False, return_alpha
         color = color.clamp(0.0, 1.0)
         activate = False
     out = ops.rasterize(xyz, rot, scale, opacity, color, view, proj, tanfov, H, W, bg=bg, apply_activations=activate,
-                        clamp_output=True, workspace=workspace, check_overflow=check_overflow, out_rgba=out_rgba)
+                        clamp_output=True, workspace=workspace, check_overflow=check_overflow, out_rgba=out_rgba, wire=wire)
     rgba = out["rgba"].view(B, T, H, W, 4)
     if return_workspace:
         return rgba, out["workspace"]

@@ -755,7 +755,7 @@ def exchange_description(gather):
         return {"collective": "RCCL all-gather of uint8 RGB frames", "algorithm": gather.algorithm,
                 "bytes_per_rank_per_step": int(gather.local[0].numel())}
     return {"collective": "RCCL all-gather of the non-background 16x16 tiles of the uint8 RGB frames (lossless), "
-                          "unpacked to dense frames on every rank",
+                          "written in wire format by the blend kernel itself, unpacked to dense frames on every rank",
             "algorithm": gather.algorithm, "bytes_per_rank_per_step": gather.wire_bytes_per_rank(),
             "capacity_tiles": gather.capacity,
             "dense_bytes_per_rank_per_step": gather.frames * gather.height * gather.width * 3}
@@ -924,13 +924,22 @@ def main():
     nchunks = len(workspaces)
     events = [[(ops.Event(), ops.Event()) for _ in range(nchunks)] for _ in range(args.steps)]
 
+    # N > 1, sparse wire, one frame group: the rasterizer writes the exchange's wire buffer itself (no pack pass)
+    direct_wire = gather is not None and gather.wire == "sparse" and len(workspaces) == 1 and os.environ.get("AMAV_WIRE_PACK") != "1"
+
     def timed_step(i):
         ops.PROFILE_EVENTS = list(events[i]) if i is not None else None
         with torch.no_grad():
-            out = step()
-        if gather is not None:  # pack + RCCL all-gather (+ unpack) on a side stream, overlapping the next step
-            hint = workspaces[0].tile_counts() if gather.wire == "sparse" and len(workspaces) == 1 else None
-            gather.submit(out, tile_hint=hint)
+            if direct_wire:
+                rgba, packed = renderer.render_tokens(tokens[0], smpl, cam, chunks=1, workspaces=workspaces,
+                                                      check_overflow=False, wire=gather.wire_target())
+                stages[:] = [packed, rgba]
+                out = rgba.unsqueeze(0)
+            else:
+                out = step()
+        if gather is not None:  # (pack +) RCCL all-gather + unpack on a side stream, overlapping the next step
+            hint = workspaces[0].tile_counts() if gather.wire == "sparse" and len(workspaces) == 1 and not direct_wire else None
+            gather.submit(out, tile_hint=hint, packed=direct_wire)
         return out
 
     for _ in range(args.warmup):

@@ -114,6 +114,15 @@ typedef struct amav_raster_args {
     /* diagnostic only: device buffer of num_frames * tiles * 6 uint64 that receives per-tile-wave clock stamps
      * (start, ranges read, sorted, blended, stored) and the list length; NULL in production */
     void *debug_stamps;
+    /* optional: the tile-sparse wire buffer of the frame exchange (amav_frames_wire_bytes(F, H, W, wire_capacity_tiles)
+     * bytes, 16-byte aligned), written by the rasterizer itself: every tile that holds a Gaussian is stored (uint8 RGB,
+     * quantised as amav_frames_to_rgb8 does, of the clamped colour), the others are background -- the result of
+     * amav_frames_pack_tiles with the rasterizer's tile counts as hint, without the pass over the fp32 frames.  Needs
+     * clamp_output = 1.  Tiles beyond the capacity are dropped and header.count > capacity tells the receivers
+     * (amav_frames_unpack_tiles raises its status flag).  NULL = off. */
+    void *wire;
+    size_t wire_bytes;
+    int64_t wire_capacity_tiles;
 } amav_raster_args;
 
 size_t amav_rasterize_workspace_bytes(int num_frames, int num_gaussians, int height, int width,

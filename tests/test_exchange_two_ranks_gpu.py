@@ -35,7 +35,7 @@ def _worker(rank, world, port, out):
                     smpl["transl"][..., 0] += 0.35 * gen
                     ws = [None]
                     rgba, _ = r.render_tokens(tokens[0], smpl, cam, workspaces=ws)
-                    shards.append((rgba.clone(), ws[0].tile_counts().clone()))
+                    shards.append((rgba.clone(), ws[0].tile_counts().clone(), (tokens[0], smpl, cam)))
                 gens.append((shards, torch.cat([ops.frames_to_rgb8(s[0]) for s in shards])))
         assert not torch.equal(gens[0][1], gens[1][1])
         ok = {}
@@ -48,12 +48,24 @@ def _worker(rank, world, port, out):
             # (the differential unpack must re-clear the tiles the body left)
             for gen in (0, 0, 0, 1, 1, 0, 1, 0, 0):
                 shards, want = gens[gen]
-                mine, hint = shards[rank]
+                mine, hint, _ = shards[rank]
                 full = gather.submit(mine, tile_hint=hint if wire == "sparse" else None)
                 gather.wait()
                 torch.cuda.synchronize()
                 key = f"{wire}/{algorithm}"
                 ok[key] = bool(torch.equal(full, want)) and not gather.overflowed() and ok.get(key, True)
+            if wire == "sparse":
+                # the same steps with the wire buffer written by the blend kernel itself (no pack pass)
+                for gen in (0, 1, 1, 0, 0, 1):
+                    shards, want = gens[gen]
+                    tok, smpl_g, cam_g = shards[rank][2]
+                    with torch.no_grad():
+                        rgba, _ = r.render_tokens(tok, smpl_g, cam_g, wire=gather.wire_target())
+                    full = gather.submit(rgba, packed=True)
+                    gather.wait()
+                    torch.cuda.synchronize()
+                    key = f"{wire}/{algorithm}/rasterizer-wire"
+                    ok[key] = bool(torch.equal(full, want)) and not gather.overflowed() and ok.get(key, True)
         flags = [None] * world
         dist.all_gather_object(flags, ok)
         if rank == 0:
@@ -78,7 +90,8 @@ def test_two_ranks_exchange_their_shards():
         for p in procs:
             p.join(timeout=400)
     assert all(p.exitcode == 0 for p in procs)
-    assert flags == [{"sparse/collective": True, "dense/collective": True, "sparse/direct": True, "dense/direct": True}] * 2
+    assert flags == [{"sparse/collective": True, "dense/collective": True, "sparse/direct": True, "dense/direct": True,
+                      "sparse/collective/rasterizer-wire": True, "sparse/direct/rasterizer-wire": True}] * 2
 
 
 def _harness_worker(rank, world, port, out):

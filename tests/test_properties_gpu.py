@@ -208,6 +208,50 @@ def test_sparse_wire_with_the_rasterizer_tile_hint(full_clip):
     assert torch.equal(dense, ops.frames_to_rgb8(rgba)) and int(status.item()) == 0
 
 
+def test_rasterizer_writes_the_wire_format_itself(full_clip):
+    """with amav_raster_args.wire the blend kernel's write-back also emits the exchange's tile-sparse
+    wire buffer (slots handed out by the binning kernel): after unpacking it equals the uint8 frames, its count and its
+    stored-tile set equal the pack pass with the tile counts as hint, and a capacity that is too small drops tiles and
+    says so -- with another background colour and with a frame size that has partial edge tiles as well."""
+    from audio_motion_avatar_amd import ops
+
+    sel, Fs = slice(60, 92), 32
+    tiles = Fs * 32 * 32
+    cap = tiles // 3
+    wire = torch.zeros(ops.frames_wire_bytes(Fs, H, W, cap), dtype=torch.uint8, device="cuda")
+    bg = (0.2, 0.5, 0.9)
+    out = raster(full_clip, sel=sel, clamp_output=True, bg=bg, wire=(wire, cap))
+    rgba, hint = out["rgba"], out["workspace"].tile_counts()
+    count, capacity = ops.frames_wire_count(wire)
+    assert capacity == cap and count == int((hint > 0).sum()) <= cap
+    dense, status = ops.frames_unpack_tiles(wire[None], 1, Fs, H, W, cap)
+    assert torch.equal(dense, ops.frames_to_rgb8(rgba)) and int(status.item()) == 0
+    packed = ops.frames_pack_tiles(rgba, cap, bg, tile_hint=hint)
+    head = lambda w: w[:64].view(torch.int32)
+    assert torch.equal(head(wire)[:8], head(packed)[:8])                      # magic, count, cap, F, T, H, W, bg
+    off = lambda w: w[64 + 4 * Fs: 64 + 4 * Fs + 4 * tiles].view(torch.int32)
+    assert torch.equal(off(wire) >= 0, off(packed) >= 0)                      # the same tiles are stored
+    assert sorted(off(wire)[off(wire) >= 0].tolist()) == list(range(count))   # slots are a permutation of 0 .. count-1
+    # too small a capacity: tiles are dropped, the header says so, the unpack raises its flag
+    small = count // 2
+    wire2 = torch.zeros(ops.frames_wire_bytes(Fs, H, W, small), dtype=torch.uint8, device="cuda")
+    raster(full_clip, sel=sel, clamp_output=True, bg=bg, wire=(wire2, small))
+    assert ops.frames_wire_count(wire2) == (count, small)
+    _, status = ops.frames_unpack_tiles(wire2[None], 1, Fs, H, W, small)
+    assert int(status.item()) == 1
+    # a frame size with partial edge tiles (the payload's out-of-image pixels read as background, as in the pack pass)
+    g = {k: v[sel][:4] for k, v in full_clip["g"].items()}
+    Hs, Ws = 200, 300
+    view, proj, tanfov, _ = ops.camera_from_intrinsics(full_clip["cam"]["intrinsic"][0, :4].float() * (Ws / W),
+                                                       full_clip["cam"]["extrinsic"][0, :4].float(), Hs, Ws)
+    t2 = 4 * ((Hs + 15) // 16) * ((Ws + 15) // 16)
+    wire3 = torch.zeros(ops.frames_wire_bytes(4, Hs, Ws, t2), dtype=torch.uint8, device="cuda")
+    o3 = ops.rasterize(g["xyz"], g["rot"], g["scale"], g["opacity"], g["color"], view, proj, tanfov, Hs, Ws,
+                       apply_activations=True, clamp_output=True, wire=(wire3, t2))
+    dense3, status = ops.frames_unpack_tiles(wire3[None], 1, 4, Hs, Ws, t2)
+    assert torch.equal(dense3, ops.frames_to_rgb8(o3["rgba"])) and int(status.item()) == 0
+
+
 def test_differential_unpack_equals_the_full_unpack_over_a_sequence_of_steps(full_clip):
     """amav_frames_unpack_tiles_delta into a REUSED dense buffer == amav_frames_unpack_tiles into a fresh one, for a
     sequence in which tiles appear, disappear and the background colour changes; an unchanged step rewrites nothing
