@@ -6,7 +6,8 @@
 // 1e-4 blend thresholds.  Everything else is laid out for CDNA4 (three launches per shard instead of upstream's
 // six launches + two CUB passes + a host sync per frame):
 //
-//   bin_kernel     ONE 1024-THREAD BLOCK PER FRAME does preprocess, per-tile counting, the scan and the key scatter
+//   bin_kernel     ONE 1024-THREAD BLOCK PER FRAME does preprocess (for shards of many frames; a launch of its own,
+//                  preprocess_kernel, when there are fewer frames than CUs), per-tile counting, the scan and the key scatter
 //                  for its frame, with the tile counters in LDS.  Device-scope atomics on scattered addresses run at
 //                  the memory side on MI355X (the eight XCD L2s are not coherent; measured 0.43 ms per 8.4 M adds);
 //                  LDS atomics do not.  Frames own fixed instance regions, so there is no cross-frame scan and no
@@ -42,6 +43,7 @@ namespace raster {
 #endif
 constexpr int kTile = AMAV_TILE;
 constexpr int kRenderWavesPerSimd = 4;  // blend kernel: one-wave workgroups resident per SIMD (register cap)
+constexpr int kFusedMinFrames = 96;  // binning: shards below this project their Gaussians in a launch of their own
 constexpr int kSortCap = 512;      // keys a wave sorts in its LDS slice (4 KiB); longer lists go to sort_big
 constexpr int kBigLdsCap = 2048;   // keys a sort_big block sorts in LDS (16 KiB); longer lists are sorted in place
 constexpr int kBigBlocks = 1280;
@@ -325,8 +327,37 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int *lds_wave, int *t
     return wave_prefix + incl - v;
 }
 
-// grid = F blocks of 1024 threads; dynamic LDS = (2*T + 48 + 3*8*(kBuckets+1)) ints: counts[T], cursor[T], classes, scratch[48]
+// Projection of every Gaussian of every frame (preprocess_one): one thread per (frame, Gaussian), any number of frames
+// fills the chip.  Round 2 ran this inside the per-frame binning block: with the reference's own window (6 frames of
+// 30 000 Gaussians) six of the 256 CUs did ~1200 instructions per Gaussian while the others idled.
 template <bool kPacked>
+__global__ __launch_bounds__(256) void preprocess_kernel(Params p) {
+    // grid = (blocks per frame, frames): the frame is block-uniform, so its camera is read with scalar loads
+    const int f = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    int up = 0;
+    if (i < p.N) {
+        const GaussRec rec = load_gaussian<kPacked>(p, f, i);
+        const uint4 rd = preprocess_one(p, f, i, rec, p.view + f * 16, p.proj + f * 16, p.tanfov[2 * f], p.tanfov[2 * f + 1], up);
+        const size_t gi = (size_t)f * p.N + i;
+        p.buf.rectd[gi] = rd;
+        if (p.out_radii) p.out_radii[gi] = (int)rd.w;
+    }
+    // upstream's instance count (3-sigma rectangles), summed per block
+    __shared__ int part[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) up += __shfl_xor(up, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = up;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int sum = part[0] + part[1] + part[2] + part[3];
+        if (sum) atomicAdd(reinterpret_cast<unsigned long long *>(&p.buf.status->total), (unsigned long long)sum);
+    }
+}
+
+// grid = F blocks of 1024 threads; dynamic LDS = (2*T + 48 + 3*8*(kBuckets+1)) ints: counts[T], cursor[T], classes, scratch[48]
+// kFused: the block also projects its frame's Gaussians (shards of >= kFusedMinFrames frames: every CU has a frame, and
+// the projection's memory traffic hides under the counting); otherwise preprocess_kernel has done that for all frames.
+template <bool kFused, bool kPacked>
 __global__ __launch_bounds__(1024) void bin_kernel(Params p) {
     extern __shared__ int bin_lds[];
     int *counts = bin_lds;
@@ -336,26 +367,44 @@ __global__ __launch_bounds__(1024) void bin_kernel(Params p) {
     for (int t = threadIdx.x; t < p.T; t += blockDim.x) counts[t] = 0;
     __syncthreads();
 
-    const float *vm = p.view + f * 16;
-    const float *pm = p.proj + f * 16;
-    const float tanx = p.tanfov[2 * f], tany = p.tanfov[2 * f + 1];
-    // phase 1: preprocess, count instances per tile (LDS atomics)
-    int upstream = 0;
-    // the next Gaussian's record is in flight while this one goes through the (long, dependent) projection maths
-    GaussRec cur = load_gaussian<kPacked>(p, f, min((int)threadIdx.x, p.N - 1));
-    for (int i = threadIdx.x; i < p.N; i += blockDim.x) {
-        const GaussRec nxt = load_gaussian<kPacked>(p, f, min(i + (int)blockDim.x, p.N - 1));
-        int up = 0;
-        const uint4 rd = preprocess_one(p, f, i, cur, vm, pm, tanx, tany, up);
-        cur = nxt;
-        upstream += up;
-        const size_t gi = (size_t)f * p.N + i;
-        p.buf.rectd[gi] = rd;
-        if (p.out_radii) p.out_radii[gi] = (int)rd.w;
-        if (rd.w) {
-            const int rx0 = rd.x & 0xffff, ry0 = rd.x >> 16, rx1 = rd.y & 0xffff, ry1 = rd.y >> 16;
-            for (int ty = ry0; ty < ry1; ++ty)
-                for (int tx = rx0; tx < rx1; ++tx) atomicAdd(&counts[ty * p.gx + tx], 1);
+    // phase 1: count instances per tile (LDS atomics)
+    if (kFused) {
+        const float *vm = p.view + f * 16;
+        const float *pm = p.proj + f * 16;
+        const float tanx = p.tanfov[2 * f], tany = p.tanfov[2 * f + 1];
+        int upstream = 0;
+        // the next Gaussian's record is in flight while this one goes through the (long, dependent) projection maths
+        GaussRec cur = load_gaussian<kPacked>(p, f, min((int)threadIdx.x, p.N - 1));
+        for (int i = threadIdx.x; i < p.N; i += blockDim.x) {
+            const GaussRec nxt = load_gaussian<kPacked>(p, f, min(i + (int)blockDim.x, p.N - 1));
+            int up = 0;
+            const uint4 rd = preprocess_one(p, f, i, cur, vm, pm, tanx, tany, up);
+            cur = nxt;
+            upstream += up;
+            const size_t gi = (size_t)f * p.N + i;
+            p.buf.rectd[gi] = rd;
+            if (p.out_radii) p.out_radii[gi] = (int)rd.w;
+            if (rd.w) {
+                const int rx0 = rd.x & 0xffff, ry0 = rd.x >> 16, rx1 = rd.y & 0xffff, ry1 = rd.y >> 16;
+                for (int ty = ry0; ty < ry1; ++ty)
+                    for (int tx = rx0; tx < rx1; ++tx) atomicAdd(&counts[ty * p.gx + tx], 1);
+            }
+        }
+        int upstream_total;
+        block_exclusive_scan(upstream, scratch, &upstream_total);
+        if (threadIdx.x == 0)
+            atomicAdd(reinterpret_cast<unsigned long long *>(&p.buf.status->total), (unsigned long long)upstream_total);
+    } else {
+        const uint4 *rect = p.buf.rectd + (size_t)f * p.N;
+        uint4 rd_next = rect[min((int)threadIdx.x, p.N - 1)];
+        for (int i = threadIdx.x; i < p.N; i += blockDim.x) {
+            const uint4 rd = rd_next;
+            rd_next = rect[min(i + (int)blockDim.x, p.N - 1)];
+            if (rd.w) {
+                const int rx0 = rd.x & 0xffff, ry0 = rd.x >> 16, rx1 = rd.y & 0xffff, ry1 = rd.y >> 16;
+                for (int ty = ry0; ty < ry1; ++ty)
+                    for (int tx = rx0; tx < rx1; ++tx) atomicAdd(&counts[ty * p.gx + tx], 1);
+            }
         }
     }
     __syncthreads();
@@ -366,8 +415,7 @@ __global__ __launch_bounds__(1024) void bin_kernel(Params p) {
     int local = 0;
     for (int k = 0; k < per; ++k)
         if (t0 + k < p.T) local += counts[t0 + k];
-    int total, upstream_total;
-    block_exclusive_scan(upstream, scratch, &upstream_total);
+    int total;
     int run = block_exclusive_scan(local, scratch, &total);
     int *off = p.buf.tile_off + (size_t)f * (p.T + 1);
     for (int k = 0; k < per; ++k) {
@@ -443,7 +491,6 @@ __global__ __launch_bounds__(1024) void bin_kernel(Params p) {
         }
     if (threadIdx.x == 0) {
         off[p.T] = total;
-        atomicAdd(reinterpret_cast<unsigned long long *>(&p.buf.status->total), (unsigned long long)upstream_total);
         atomicAdd(reinterpret_cast<unsigned long long *>(&p.buf.status->emitted), (unsigned long long)total);
         atomicMax(reinterpret_cast<unsigned long long *>(&p.buf.status->max_frame), (unsigned long long)total);
         if (!fits) atomicExch(&p.buf.status->overflow, 1);
@@ -1617,12 +1664,11 @@ extern "C" int amav_rasterize_forward(const amav_raster_args *a, void *stream_) 
     }
 
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    static const hipError_t attr[2] = {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&bin_kernel<false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&bin_kernel<true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)};
-    if (attr[0] != hipSuccess || attr[1] != hipSuccess)
+    static const hipError_t attr[3] = {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&bin_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&bin_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&bin_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)};
+    if (attr[0] != hipSuccess || attr[1] != hipSuccess || attr[2] != hipSuccess)
         return fail(AMAV_ERR_LAUNCH, "amav_rasterize_forward: cannot raise the dynamic LDS limit");
     // packed-record fast path: the attributes are the xyz|opacity|rot|scale|color views of one [.., 16] buffer
     const float *b0 = a->means3d.ptr;
@@ -1639,10 +1685,21 @@ extern "C" int amav_rasterize_forward(const amav_raster_args *a, void *stream_) 
     if (p.wire_header && zero_async(p.wire_header, (size_t)kWireHeaderInts * 4, stream) != hipSuccess)
         return fail(AMAV_ERR_LAUNCH, "amav_rasterize_forward: wire header clear failed");
 
-    if (packed)
-        bin_kernel<true><<<F, 1024, bin_lds, stream>>>(p);
+    // Few frames (the reference's own window is 6): the projection of ALL Gaussians runs as its own launch over the
+    // whole chip and the per-frame blocks only count and scatter; a shard of many frames keeps the projection inside
+    // the per-frame block (one frame per CU anyway; measured 250 x 10 000: 0.12 ms fused, 0.20 ms split -- 6 x 30 000:
+    // 81 us split, of which 15 us projection).
+    if (F < kFusedMinFrames && F <= 65535) {
+        const dim3 pre_grid((unsigned)((N + 255) / 256), (unsigned)F);
+        if (packed)
+            preprocess_kernel<true><<<pre_grid, 256, 0, stream>>>(p);
+        else
+            preprocess_kernel<false><<<pre_grid, 256, 0, stream>>>(p);
+        bin_kernel<false, false><<<F, 1024, bin_lds, stream>>>(p);
+    } else if (packed)
+        bin_kernel<true, true><<<F, 1024, bin_lds, stream>>>(p);
     else
-        bin_kernel<false><<<F, 1024, bin_lds, stream>>>(p);
+        bin_kernel<true, false><<<F, 1024, bin_lds, stream>>>(p);
     sort_big_kernel<<<kBigBlocks, 256, 0, stream>>>(p);
     // persistent grid: the waves the chip holds at once (a multiple of kQueues)
     const unsigned blocks = render_grid(a->out_inv_depth != nullptr);
