@@ -57,6 +57,14 @@ class BodyTables(ctypes.Structure):
 SIGNATURES = {
     "amav_version": (ctypes.c_char_p, []),
     "amav_set_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p]),
+    "amav_gemm_split_fp16": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                            ctypes.c_float, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
+                                            ctypes.c_void_p]),
+    "amav_gemm_split_fp16_tune": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                                 ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
+                                                 ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_float),
+                                                 ctypes.POINTER(ctypes.c_float), ctypes.c_void_p]),
+    "amav_gemm_library_version": (ctypes.c_char_p, []),
     "amav_last_error": (ctypes.c_char_p, []),
     "amav_device_count": (ctypes.c_int, []),
     "amav_event_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p)]),

@@ -1,0 +1,176 @@
+// Library GEMM entry for the fp16 x 2 split projections of the transformer step: out[rows, n] (fp32) =
+// alpha * a[rows, k3] (fp16) x w[n, k3]^T (fp16), fp32 accumulate -- the three partial products of an fp32-equivalent
+// nn.Linear (src/models/transformers.py:70-84, 448, 505) concatenated along K.  The arithmetic
+// is hipBLASLt's; what this file adds is the choice of kernel: hipBLASLt's first heuristic answer is 39 % slower than
+// its best kernel for the 2048 -> 512 feed-forward output projection (K' = 6144: 0.066 vs 0.040 ms at 6304 rows,
+// tools/hipblaslt_probe.cpp), so the caller may name the algorithm by its library index (found once per shape by
+// amav_gemm_split_fp16_tune, shipped in gemm_split_tuning_gfx950.csv) and gets the heuristic's choice otherwise.
+#include <hipblaslt/hipblaslt-ext.hpp>
+#include <hipblaslt/hipblaslt.h>
+
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
+#include "amav_common.h"
+
+namespace amav {
+namespace gemm {
+
+struct Plan {
+    hipblasLtMatmulDesc_t desc = nullptr;
+    hipblasLtMatrixLayout_t la = nullptr, lb = nullptr, ld = nullptr;
+    hipblasLtMatmulAlgo_t algo;
+    size_t workspace = 0;
+    bool ok = false;
+};
+
+static hipblasLtHandle_t handle() {
+    static hipblasLtHandle_t h = [] {
+        hipblasLtHandle_t x = nullptr;
+        return hipblasLtCreate(&x) == HIPBLAS_STATUS_SUCCESS ? x : nullptr;
+    }();
+    return h;
+}
+
+static std::mutex g_lock;
+static std::map<std::tuple<long long, int, int, int>, Plan> g_plans;  // (rows, n, k3, algo index)
+
+static bool make_layouts(Plan &p, long long rows, int n, int k3) {
+    const hipblasOperation_t opT = HIPBLAS_OP_T, opN = HIPBLAS_OP_N;
+    return hipblasLtMatmulDescCreate(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F) == HIPBLAS_STATUS_SUCCESS &&
+           hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &opT, sizeof(opT)) == HIPBLAS_STATUS_SUCCESS &&
+           hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &opN, sizeof(opN)) == HIPBLAS_STATUS_SUCCESS &&
+           // row-major [n, k3] weights = column-major k3 x n; row-major [rows, k3] activations = k3 x rows; out = n x rows
+           hipblasLtMatrixLayoutCreate(&p.la, HIP_R_16F, k3, n, k3) == HIPBLAS_STATUS_SUCCESS &&
+           hipblasLtMatrixLayoutCreate(&p.lb, HIP_R_16F, k3, rows, k3) == HIPBLAS_STATUS_SUCCESS &&
+           hipblasLtMatrixLayoutCreate(&p.ld, HIP_R_32F, n, rows, n) == HIPBLAS_STATUS_SUCCESS;
+}
+
+// the plan for (shape, algorithm index); index < 0 or an index this library build does not know: the heuristic's choice
+static const Plan *plan_for(long long rows, int n, int k3, int index, size_t ws_bytes) {
+    std::lock_guard<std::mutex> guard(g_lock);
+    const auto key = std::make_tuple(rows, n, k3, index);
+    auto it = g_plans.find(key);
+    if (it != g_plans.end()) return it->second.ok && it->second.workspace <= ws_bytes ? &it->second : nullptr;
+    Plan p;
+    const float one = 1.f, zero = 0.f;
+    if (handle() && make_layouts(p, rows, n, k3)) {
+        if (index >= 0) {
+            std::vector<int> idx{index};
+            std::vector<hipblasLtMatmulHeuristicResult_t> res;
+            if (hipblaslt_ext::getAlgosFromIndex(handle(), idx, res) == HIPBLAS_STATUS_SUCCESS && !res.empty()) {
+                size_t need = 0;
+                if (hipblaslt_ext::matmulIsAlgoSupported(handle(), p.desc, &one, p.la, p.lb, &zero, p.ld, p.ld, res[0].algo, need) ==
+                    HIPBLAS_STATUS_SUCCESS) {
+                    p.algo = res[0].algo, p.workspace = need, p.ok = true;
+                }
+            }
+        }
+        if (!p.ok) {
+            hipblasLtMatmulPreference_t pref = nullptr;
+            hipblasLtMatmulHeuristicResult_t heur[1];
+            int got = 0;
+            if (hipblasLtMatmulPreferenceCreate(&pref) == HIPBLAS_STATUS_SUCCESS &&
+                hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &ws_bytes, sizeof(ws_bytes)) ==
+                    HIPBLAS_STATUS_SUCCESS &&
+                hipblasLtMatmulAlgoGetHeuristic(handle(), p.desc, p.la, p.lb, p.ld, p.ld, pref, 1, heur, &got) == HIPBLAS_STATUS_SUCCESS &&
+                got > 0) {
+                p.algo = heur[0].algo, p.workspace = heur[0].workspaceSize, p.ok = true;
+            }
+            if (pref) hipblasLtMatmulPreferenceDestroy(pref);
+        }
+    }
+    auto &slot = g_plans[key] = p;
+    return slot.ok && slot.workspace <= ws_bytes ? &slot : nullptr;
+}
+
+}  // namespace gemm
+}  // namespace amav
+
+using namespace amav;
+
+static int check_gemm_args(const char *who, int64_t rows, int n, int k3, const void *a, const void *w, const float *out) {
+    AMAV_REQUIRE(rows > 0 && rows < (1ll << 31) && n > 0 && k3 > 0 && k3 % 8 == 0, "%s: bad sizes rows=%lld n=%d k3=%d", who,
+                 (long long)rows, n, k3);
+    AMAV_REQUIRE(a && w && out, "%s: NULL pointer", who);
+    AMAV_REQUIRE(((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(out)) & 15) == 0,
+                 "%s: operands must be 16-byte aligned", who);
+    return AMAV_OK;
+}
+
+extern "C" int amav_gemm_split_fp16(int64_t rows, int n, int k3, const void *a, const void *w, float alpha, float *out,
+                                    int algo_index, void *workspace, size_t workspace_bytes, void *stream) {
+    if (int rc = check_gemm_args("amav_gemm_split_fp16", rows, n, k3, a, w, out)) return rc;
+    const gemm::Plan *p = gemm::plan_for(rows, n, k3, algo_index, workspace ? workspace_bytes : 0);
+    if (!p) return fail(AMAV_ERR_LAUNCH, "amav_gemm_split_fp16: hipBLASLt has no kernel for rows=%lld n=%d k=%d within %zu B of workspace",
+                        (long long)rows, n, k3, workspace_bytes);
+    const float beta = 0.f;
+    hipblasLtMatmulAlgo_t algo = p->algo;
+    const hipblasStatus_t st = hipblasLtMatmul(gemm::handle(), p->desc, &alpha, w, p->la, a, p->lb, &beta, out, p->ld, out, p->ld, &algo,
+                                               workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+    if (st != HIPBLAS_STATUS_SUCCESS) return fail(AMAV_ERR_LAUNCH, "amav_gemm_split_fp16: hipblasLtMatmul failed (%d)", (int)st);
+    return AMAV_OK;
+}
+
+extern "C" int amav_gemm_split_fp16_tune(int64_t rows, int n, int k3, const void *a, const void *w, float *out, void *workspace,
+                                         size_t workspace_bytes, int repeats, int copies, int32_t *best_index, float *best_ms,
+                                         float *heuristic_ms, void *stream_) {
+    if (int rc = check_gemm_args("amav_gemm_split_fp16_tune", rows, n, k3, a, w, out)) return rc;
+    AMAV_REQUIRE(best_index && best_ms && heuristic_ms && repeats > 0 && copies > 0, "amav_gemm_split_fp16_tune: NULL result pointer");
+    // `copies` > 1: a, w and out are `copies` consecutive operand sets and run i uses set i % copies, so that a kernel is
+    // timed as it runs inside the transformer step (weights and activations come from MALL / HBM, not from a hot L2)
+    const size_t a_step = (size_t)rows * k3 * 2, w_step = (size_t)n * k3 * 2, o_step = (size_t)rows * n * 4;
+    auto A = [&](int i) { return static_cast<const char *>(a) + (size_t)(i % copies) * a_step; };
+    auto W = [&](int i) { return static_cast<const char *>(w) + (size_t)(i % copies) * w_step; };
+    auto O = [&](int i) { return reinterpret_cast<float *>(reinterpret_cast<char *>(out) + (size_t)(i % copies) * o_step); };
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    gemm::Plan p;
+    AMAV_REQUIRE(gemm::handle() && gemm::make_layouts(p, rows, n, k3), "amav_gemm_split_fp16_tune: hipBLASLt set-up failed");
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(AMAV_ERR_LAUNCH, "amav_gemm_split_fp16_tune: events");
+    const float one = 1.f, zero = 0.f;
+    auto time_algo = [&](hipblasLtMatmulAlgo_t algo, float *ms) {
+        size_t need = 0;
+        if (hipblaslt_ext::matmulIsAlgoSupported(gemm::handle(), p.desc, &one, p.la, p.lb, &zero, p.ld, p.ld, algo, need) != HIPBLAS_STATUS_SUCCESS ||
+            need > workspace_bytes)
+            return false;
+        for (int i = 0; i < 2; ++i)
+            if (hipblasLtMatmul(gemm::handle(), p.desc, &one, W(i), p.la, A(i), p.lb, &zero, O(i), p.ld, O(i), p.ld, &algo, workspace,
+                                workspace_bytes, stream) != HIPBLAS_STATUS_SUCCESS)
+                return false;
+        (void)hipEventRecord(e0, stream);
+        for (int i = 0; i < repeats; ++i)
+            (void)hipblasLtMatmul(gemm::handle(), p.desc, &one, W(i), p.la, A(i), p.lb, &zero, O(i), p.ld, O(i), p.ld, &algo, workspace,
+                                  workspace_bytes, stream);
+        (void)hipEventRecord(e1, stream);
+        if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(ms, e0, e1) != hipSuccess) return false;
+        *ms /= (float)repeats;
+        return true;
+    };
+    *best_index = -1, *best_ms = 1e30f, *heuristic_ms = -1.f;
+    const gemm::Plan *h = gemm::plan_for(rows, n, k3, -1, workspace_bytes);
+    if (h) (void)time_algo(h->algo, heuristic_ms);
+    std::vector<hipblasLtMatmulHeuristicResult_t> all;
+    if (hipblaslt_ext::getAllAlgos(gemm::handle(), hipblaslt_ext::GemmType::HIPBLASLT_GEMM, HIPBLAS_OP_T, HIPBLAS_OP_N, HIP_R_16F, HIP_R_16F,
+                                   HIP_R_32F, HIP_R_32F, HIPBLAS_COMPUTE_32F, all) != HIPBLAS_STATUS_SUCCESS)
+        return fail(AMAV_ERR_LAUNCH, "amav_gemm_split_fp16_tune: getAllAlgos failed");
+    for (auto &r : all) {
+        float ms;
+        if (time_algo(r.algo, &ms) && ms < *best_ms) *best_ms = ms, *best_index = hipblaslt_ext::getIndexFromAlgo(r.algo);
+    }
+    (void)hipEventDestroy(e0), (void)hipEventDestroy(e1);
+    return *best_index >= 0 ? AMAV_OK : fail(AMAV_ERR_LAUNCH, "amav_gemm_split_fp16_tune: no algorithm ran");
+}
+
+extern "C" const char *amav_gemm_library_version(void) {
+    static char buf[64] = {0};
+    if (!buf[0]) {
+        int v = 0;
+        if (gemm::handle() && hipblasLtGetVersion(gemm::handle(), &v) == HIPBLAS_STATUS_SUCCESS) snprintf(buf, sizeof(buf), "hipblaslt-%d", v);
+        else snprintf(buf, sizeof(buf), "hipblaslt-unknown");
+    }
+    return buf;
+}

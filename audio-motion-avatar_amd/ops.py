@@ -611,6 +611,50 @@ def selfattn(q, k, v, heads, scale=None, bounds=None):
     return out
 
 
+_GEMM_WS = {}
+
+
+def gemm_split_fp16(a, w, alpha=1.0, algo_index=-1):
+    """a [rows, k3] fp16 x w [n, k3]^T fp16 -> [rows, n] fp32 (fp32 accumulate, scaled by alpha) through hipBLASLt with
+    the kernel named by `algo_index` (-1: the library's own heuristic; include/amav.h, amav_gemm_split_fp16)."""
+    a, w = _need(a, "a", torch.float16), _need(w, "w", torch.float16)
+    if a.dim() != 2 or w.dim() != 2 or a.shape[1] != w.shape[1] or not a.is_contiguous() or not w.is_contiguous():
+        raise AmavError("gemm_split_fp16: need contiguous a [rows, k3] and w [n, k3]")
+    out = torch.empty(a.shape[0], w.shape[0], device=a.device)
+    ws = _GEMM_WS.get(a.device)
+    if ws is None:
+        ws = _GEMM_WS[a.device] = torch.empty(32 << 20, dtype=torch.uint8, device=a.device)
+    check(_lib.lib().amav_gemm_split_fp16(a.shape[0], w.shape[0], a.shape[1], a.data_ptr(), w.data_ptr(), float(alpha),
+                                          out.data_ptr(), int(algo_index), ws.data_ptr(), ws.numel(), _stream()),
+          "amav_gemm_split_fp16")
+    return out
+
+
+def gemm_split_fp16_tune(a, w, repeats=10):
+    """Times every hipBLASLt kernel on these operands (synchronises; seconds per shape) -> (best index, best ms,
+    ms of the library's heuristic choice).  a [copies, rows, k3], w [copies, n, k3] (or 2-D: one set): run i uses set
+    i % copies, so with several sets the kernels are timed out of MALL / HBM as inside the transformer step."""
+    a, w = _need(a, "a", torch.float16), _need(w, "w", torch.float16)
+    if a.dim() == 2:
+        a, w = a[None], w[None]
+    copies = a.shape[0]
+    if w.shape[0] != copies or not a.is_contiguous() or not w.is_contiguous():
+        raise AmavError("gemm_split_fp16_tune: need contiguous a [copies, rows, k3], w [copies, n, k3]")
+    out = torch.empty(copies, a.shape[1], w.shape[1], device=a.device)
+    a, w = a.view(-1, a.shape[-1]), w.view(-1, w.shape[-1])
+    rows, n = a.shape[0] // copies, w.shape[0] // copies
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=a.device)
+    idx, best, heur = ctypes.c_int32(-1), ctypes.c_float(0), ctypes.c_float(0)
+    check(_lib.lib().amav_gemm_split_fp16_tune(rows, n, a.shape[1], a.data_ptr(), w.data_ptr(), out.data_ptr(),
+                                               ws.data_ptr(), ws.numel(), int(repeats), int(copies), ctypes.byref(idx),
+                                               ctypes.byref(best), ctypes.byref(heur), _stream()), "amav_gemm_split_fp16_tune")
+    return int(idx.value), float(best.value), float(heur.value)
+
+
+def gemm_library_version() -> str:
+    return _lib.lib().amav_gemm_library_version().decode()
+
+
 SPLIT_BF16X3, SPLIT_FP16X2 = 0, 1  # include/amav.h
 
 

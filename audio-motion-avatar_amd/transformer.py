@@ -33,7 +33,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import ops, tuning
 
 _MEMO = {}  # (name, ids of the tensors it was derived from) -> (their versions, weak references, value)
 SPLIT_GEMM_MIN_ROWS = 256  # below this the operand split costs more than the faster GEMM saves
@@ -82,17 +82,13 @@ def _split_weight_fp16(weight):
     return _memo("fp16x2", (weight,), make)
 
 
-_ZERO_BIAS = {}
-
-
 def gemm_fp16(a, a_exp, weight):
     """a: fp16 x 2 activation operand [rows, 3K] pre-scaled by 2^a_exp -> [rows, N] fp32 = x weight^T, scaled back
     exactly through the GEMM's alpha (beta = 0: the `input` of addmm is a placeholder)."""
     b, b_exp = _split_weight_fp16(weight)
-    key = (a.device, weight.shape[0])
-    if key not in _ZERO_BIAS:
-        _ZERO_BIAS[key] = torch.zeros(weight.shape[0], device=a.device)
-    return torch.addmm(_ZERO_BIAS[key], a, b.t(), beta=0.0, alpha=2.0 ** -(a_exp + b_exp), out_dtype=torch.float32)
+    # hipBLASLt through the C ABI, with the kernel the shipped table names for this shape (tuning.split_gemm_index: the
+    # library's first heuristic answer -- what torch.addmm runs -- is 5-18 % slower on these four shapes)
+    return ops.gemm_split_fp16(a, b, 2.0 ** -(a_exp + b_exp), tuning.split_gemm_index(a.shape[0], b.shape[0], a.shape[1]))
 
 
 def split_gemm_ok(rows, K):

@@ -40,3 +40,28 @@ def use_tuned_gemms(path=None) -> bool:
         return False
     _loaded["active"] = True
     return True
+
+
+# ---- fp16 x 2 split projections: hipBLASLt kernel per shape (csrc/gemm.hip) ------------------------------------------
+SPLIT_TUNING_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_split_tuning_gfx950.csv")
+_split = {"table": None}
+
+
+def split_gemm_index(rows: int, n: int, k3: int) -> int:
+    """hipBLASLt algorithm index for out[rows, n] = a[rows, k3] x w[n, k3]^T (fp16 in, fp32 out) from the shipped table
+    (tools/tune_split_gemms.py), or -1 = the library's own heuristic: unknown shape, AMAV_TUNED_GEMMS=0, or a table that
+    was made with another hipBLASLt build / architecture (its first line names both; indices are only meaningful there)."""
+    if _split["table"] is None:
+        table = {}
+        if os.environ.get("AMAV_TUNED_GEMMS", "1") != "0" and os.path.exists(SPLIT_TUNING_FILE) and torch.cuda.is_available():
+            from . import ops
+
+            with open(SPLIT_TUNING_FILE) as fh:
+                lines = [ln.strip() for ln in fh if ln.strip()]
+            arch = torch.cuda.get_device_properties(0).gcnArchName.split(":")[0]
+            if lines and lines[0].lstrip("# ").split() == [ops.gemm_library_version(), arch]:
+                for ln in lines[1:]:
+                    r, nn, kk, idx = (int(x) for x in ln.split(",")[:4])
+                    table[(r, nn, kk)] = idx
+        _split["table"] = table
+    return _split["table"].get((int(rows), int(n), int(k3)), -1)

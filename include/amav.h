@@ -416,6 +416,24 @@ int amav_rows_norm(int64_t rows, int channels, const float *x_dev, const float *
 int amav_unpool_merge(int64_t rows, int channels, const float *x_dev, const float *scale_dev, const float *shift_dev,
                       const float *up_dev, const int64_t *cluster_dev, float *skip_dev, float *sum_dev, void *stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Library GEMM of the fp16 x 2 split projections: out[rows, n] fp32 = alpha * a[rows, k3] x
+ * w[n, k3]^T with fp16 operands and fp32 accumulation -- the three partial products of an fp32-equivalent nn.Linear
+ * (src/models/transformers.py:70-84, 448, 505) concatenated along K.  hipBLASLt does the arithmetic; `algo_index` names
+ * one of its kernels (as found by amav_gemm_split_fp16_tune for this shape on this library build), -1 or an index the
+ * library does not accept selects its own heuristic's choice.  `workspace` may be NULL for kernels that need none.
+ * amav_gemm_split_fp16_tune synchronises: it times every kernel of the library on the given operands (`repeats` runs
+ * each; with `copies` > 1 the three buffers hold that many consecutive operand sets and run i uses set i % copies, which
+ * times a kernel as it runs inside the step, not out of a hot L2) and reports the fastest one's index and time next to
+ * the heuristic choice's time.
+ * amav_gemm_library_version: the library build the indices belong to. */
+int amav_gemm_split_fp16(int64_t rows, int n, int k3, const void *a_fp16, const void *w_fp16, float alpha, float *out,
+                         int algo_index, void *workspace, size_t workspace_bytes, void *stream);
+int amav_gemm_split_fp16_tune(int64_t rows, int n, int k3, const void *a_fp16, const void *w_fp16, float *out, void *workspace,
+                              size_t workspace_bytes, int repeats, int copies, int32_t *best_index, float *best_ms,
+                              float *heuristic_ms, void *stream);
+const char *amav_gemm_library_version(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -246,3 +246,24 @@ def test_fused_block_with_trained_like_statistics(monkeypatch, sparse_gains):
     assert ok == [not sparse_gains] * 2, [blk._fp16_overshoot for blk in net.transformer_blocks]
     assert torch.isfinite(y).all()
     assert (y - y32).abs().max() <= 2e-5 * max(1.0, y32.abs().max().item())
+
+
+@pytest.mark.parametrize("rows,n,k3", [(6304, 512, 6144), (6304, 4096, 1536), (300, 40, 192)])
+def test_library_gemm_entry_equals_torch_for_every_selectable_kernel(rows, n, k3):
+    """amav_gemm_split_fp16 (csrc/gemm.hip): hipBLASLt with the kernel the shipped table names for the shape (or the
+    library's heuristic for unknown shapes / indices).  Whatever kernel runs, the result is the fp16-in / fp32-accumulate
+    product; against torch.mm's it may differ only by the summation order of exact partial products."""
+    from audio_motion_avatar_amd import ops, tuning
+
+    g = torch.Generator(device="cuda").manual_seed(rows + n)
+    a = (torch.randn(rows, k3, device="cuda", generator=g) * 50).half()
+    w = (torch.randn(n, k3, device="cuda", generator=g) * 50).half()
+    ref = torch.mm(a.double(), w.double().t())
+    scale = float(ref.abs().max())
+    idx = tuning.split_gemm_index(rows, n, k3)
+    for index in sorted({idx, -1, 123456789}):   # tuned, heuristic, and an index no library knows (falls back)
+        got = ops.gemm_split_fp16(a, w, 0.25, index)
+        assert got.shape == (rows, n) and float((got.double() - 0.25 * ref).abs().max()) <= 2e-6 * scale, index
+    assert ops.gemm_library_version().startswith("hipblaslt-")
+    with pytest.raises(ops.AmavError):
+        ops.gemm_split_fp16(a[:, :-4].contiguous(), w[:, :-4].contiguous())   # k3 not a multiple of 8
