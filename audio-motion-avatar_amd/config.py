@@ -50,7 +50,10 @@ class RendererConfig:
     enc_patch_size: Tuple[int, ...] = (512, 512, 512, 512, 512)
     dec_patch_size: Tuple[int, ...] = (512, 512, 512, 512)
     enable_flash: bool = False
-    refiner_clouds_per_pass: int = 8  # frames refined together (bounds the working set; frames are independent)
+    refiner_clouds_per_pass: int = 32  # frames refined together: the network is ~900 launches per pass whatever the number of
+    #                                   clouds, so larger passes cost less per frame (10 k points: 8 -> 2.26, 16 -> 1.85,
+    #                                   32 -> 1.62 ms per frame); frames are independent, the split changes nothing
+    refiner_points_per_pass: int = 320_000  # ... but a pass holds at most this many points (working set ~0.4 MB per 1 k points)
     use_gaussian_splatting: bool = True
     gaussian_feature_dim: int = 256
     rgb: bool = True

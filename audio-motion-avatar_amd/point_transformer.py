@@ -342,11 +342,12 @@ class PTv3Encoder(nn.Module):
             dec_num_head=cfg.dec_num_head, enc_patch_size=cfg.enc_patch_size, dec_patch_size=cfg.dec_patch_size,
             enable_flash=getattr(cfg, "enable_flash", False))
         self.grid_resolution = 100
-        self.clouds_per_pass = int(getattr(cfg, "refiner_clouds_per_pass", 8))
+        self.clouds_per_pass = int(getattr(cfg, "refiner_clouds_per_pass", 32))
+        self.points_per_pass = int(getattr(cfg, "refiner_points_per_pass", 320_000))
 
     def forward(self, pts, feats):
         """pts [B,N,3], feats [B,N,C] -> [B*N, dec_channels[0]]."""
         B = pts.shape[0]
-        outs = [self.point_transformer(pts[s:s + self.clouds_per_pass], feats[s:s + self.clouds_per_pass])
-                for s in range(0, B, self.clouds_per_pass)]
+        step = max(1, min(self.clouds_per_pass, self.points_per_pass // max(int(pts.shape[1]), 1)))
+        outs = [self.point_transformer(pts[s:s + step], feats[s:s + step]) for s in range(0, B, step)]
         return outs[0] if len(outs) == 1 else torch.cat(outs)

@@ -150,7 +150,8 @@ class Renderer(nn.Module):
         F, N, _ = points.shape
         R = self._plane_resolution(triplane_tokens)
         planes = triplane_tokens.view(F, triplane_tokens.shape[1], 3, R, R).permute(0, 2, 1, 3, 4)
-        step = max(1, int(getattr(self.cfg, "refiner_clouds_per_pass", 8)))
+        step = max(1, min(int(getattr(self.cfg, "refiner_clouds_per_pass", 32)),
+                          int(getattr(self.cfg, "refiner_points_per_pass", 320_000)) // max(N, 1)))
         refined = torch.empty_like(points)
         for s in range(0, F, step):
             pts = points[s:s + step].contiguous()

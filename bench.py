@@ -366,7 +366,7 @@ def oracle_render(renderer, cfg, tokens, smpl_params, cam):
     return o_rast.render_batch(g, cam["intrinsic"], cam["extrinsic"], cfg.image_size, full=True)
 
 
-def measure_point_refiner(args, device, with_cpu, frames=16):
+def measure_point_refiner(args, device, with_cpu, frames=32):
     """The `point_refiner` object of the default line (the reference's default renderer runs it,
     renderer.py:143-151): the same synthetic frames with cfg.no_point_refiner=False (ptv3_encoder.yaml), LBS points ->
     triplane features -> PointTransformerV3 -> offset MLP, timed with HIP events; roofline of its dominant kernel (the
