@@ -104,8 +104,9 @@ def pmc_mfma_busy(kernel_substr):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed steps (default: 200 x ~1 ms for the render workload, 100 for stress, 3 x 1.2 s for full)")
+    ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--frames", type=int, default=250, help="frames per GPU per step (shard size)")
     ap.add_argument("--gaussians", type=int, default=10000)
     ap.add_argument("--image", type=int, default=512)
@@ -871,6 +872,10 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    if args.steps is None:
+        args.steps = {"render": 200, "stress": 100, "full": 3}[args.workload]
+    if args.warmup is None:
+        args.warmup = {"render": 10, "stress": 5, "full": 1}[args.workload]
     if args.workload == "stress":
         args.gaussians, args.image = 50000, 1024
         if args.frames == 250:

@@ -15,7 +15,7 @@ step() { # name, seconds, command...
 }
 step pytest 800 python -m pytest tests -m gpu -q -x --durations=8 || exit 1
 step smoke 200 python -c "import __graft_entry__ as g; g.smoke()" || exit 1
-timeout -k 10 500 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_${tag}.json 2> gpurun_out/bench_${tag}.err
+timeout -k 10 500 python bench.py > gpurun_out/bench_${tag}.json 2> gpurun_out/bench_${tag}.err
 echo "[bench] rc=$?"; tail -c 300 gpurun_out/bench_${tag}.err
 python - <<PY
 import json
