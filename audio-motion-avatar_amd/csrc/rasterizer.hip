@@ -1323,7 +1323,12 @@ __global__ __launch_bounds__(64, kRenderWavesPerSimd) void render_kernel(Params 
                 const float4 *g = geom + (size_t)id * 3;
                 g0 = g[0], g1 = g[1], g2 = g[2];
             };
+#ifndef AMAV_STAMP_DETAIL
             AMAV_STAMP(1);
+#endif
+#ifdef AMAV_STAMP_DETAIL
+            const unsigned long long own_0 = __builtin_amdgcn_s_memrealtime();
+#endif
             if (!ready) {  // not prepared under the previous tile: the wave's first tile, lists of 257 .. 512 keys
                 const unsigned long long *keys = p.buf.keys + (size_t)f * p.cap_per_frame + cur.beg;
                 if (local) {
@@ -1377,6 +1382,14 @@ __global__ __launch_bounds__(64, kRenderWavesPerSimd) void render_kernel(Params 
             bool ready_next = false;
             const float4 *geom_next = geom;
 
+#ifdef AMAV_STAMP_DETAIL  /* diagnostic build (tools/stamp_render.py --detail): wave-time inside the blend loops / fill */
+            unsigned long long t_asm = 0, t_fill = 0, t_prep = 0, t_stage = 0, t_own = __builtin_amdgcn_s_memrealtime() - own_0;
+#define AMAV_TIC(x) const unsigned long long x##_0 = __builtin_amdgcn_s_memrealtime()
+#define AMAV_TOC(x, acc) acc += __builtin_amdgcn_s_memrealtime() - x##_0
+#else
+#define AMAV_TIC(x)
+#define AMAV_TOC(x, acc)
+#endif
             int qalive = 15;  // quadrants that still have an unfinished pixel (wave-uniform)
             int fill_left = fill_chunk;                                       // background tiles owed by this tile ...
             const int fill_round = (fill_chunk * 64 + n - 1) / max(n, 64) + 0;  // ... per staging round (ceil(n / 64) rounds)
@@ -1410,6 +1423,7 @@ __global__ __launch_bounds__(64, kRenderWavesPerSimd) void render_kernel(Params 
                     }
                 }
                 if (more) {
+                    AMAV_TIC(s0);
                     // quadrant mask of this ln's Gaussian: which live 8x8 quadrants its alpha >= 1/255 box can reach
                     int qm = 0;
                     if (base + ln < n) {
@@ -1444,15 +1458,20 @@ __global__ __launch_bounds__(64, kRenderWavesPerSimd) void render_kernel(Params 
                     if (n2) put(2, m2, n2, 4);
                     if (n3) put(3, m3, n3, 8);
                     wave_sync();
+                    AMAV_TOC(s0, t_stage);
 #if AMAV_ABLATE != 5 && AMAV_ABLATE != 7
                     // this round's share of the background (see the kernel's header), from the ids already in registers
+                    { AMAV_TIC(f0);
                     for (int k = 0; k < fill_round && fill_left > 0 && fill.pos < fill.have; ++k, --fill_left)
                         fill_tile_at<kInvDepth>(p, fill, ln);
+                    AMAV_TOC(f0, t_fill); }
 #endif
                     // prefetch the next round's records while this one is blended
                     if (!last && base + 64 + ln < n) load_records(base + 64 + ln);
 #if AMAV_ABLATE != 3 && AMAV_ABLATE != 7  /* diagnostic builds: no blending at all */
+                    { AMAV_TIC(a0);
                     if (n0 && !blend_quadrant<kInvDepth>(lists_base, (n0 + 1) >> 1, lxf0, lyf0, T0, R0, G0, B0, D0)) qalive &= ~1;
+                    AMAV_TOC(a0, t_asm); }
 #endif
                 }
                 if (base == 0) {  // the tile after next: its position has come back, request its queue entry
@@ -1461,12 +1480,15 @@ __global__ __launch_bounds__(64, kRenderWavesPerSimd) void render_kernel(Params 
                 }
 #if AMAV_ABLATE != 3 && AMAV_ABLATE != 7
                 if (more) {
+                    AMAV_TIC(a1);
                     if (n1 && !blend_quadrant<kInvDepth>(lists_base + kListStride * 4u, (n1 + 1) >> 1, lxf1, lyf0, T1, R1, G1, B1, D1)) qalive &= ~2;
+                    AMAV_TOC(a1, t_asm);
                 }
 #endif
                 if (last) {
                     // ---- next tile, steps 2 and 3: sort its keys into the id area (this tile has requested its last
                     // records, and lists 0 / 1 are done with), then request the records of its first staging round
+                    AMAV_TIC(p0);
                     if (nxt.n > 0 && nxt.n <= kPrepCap) {
                         sort_prefetched(pk, nxt.n, L.keys, prep_cnt, order_l, ln);
                         if (ln < nxt.n) {
@@ -1481,11 +1503,14 @@ __global__ __launch_bounds__(64, kRenderWavesPerSimd) void render_kernel(Params 
                         }
                         ready_next = true;
                     }
+                    AMAV_TOC(p0, t_prep);
                 }
 #if AMAV_ABLATE != 3 && AMAV_ABLATE != 7
                 if (more) {
+                    AMAV_TIC(a2);
                     if (n2 && !blend_quadrant<kInvDepth>(lists_base + kListStride * 8u, (n2 + 1) >> 1, lxf0, lyf1, T2, R2, G2, B2, D2)) qalive &= ~4;
                     if (n3 && !blend_quadrant<kInvDepth>(lists_base + kListStride * 12u, (n3 + 1) >> 1, lxf1, lyf1, T3, R3, G3, B3, D3)) qalive &= ~8;
+                    AMAV_TOC(a2, t_asm);
                 }
 #endif
 
@@ -1501,6 +1526,12 @@ __global__ __launch_bounds__(64, kRenderWavesPerSimd) void render_kernel(Params 
                          :
                          : "memory");
 
+#ifdef AMAV_STAMP_DETAIL
+            if (p.stamps && lane == 0) {  // slots 1 and 2 carry durations in this build: blend loops; next tile's sort + fill
+                p.stamps[(size_t)item * 6 + 1] = t_asm;
+                p.stamps[(size_t)item * 6 + 2] = (t_prep << 48) | ((t_fill & 0xffffull) << 32) | ((t_stage & 0xffffull) << 16) | (t_own & 0xffffull);
+            }
+#endif
             AMAV_STAMP(3);
             // ---- write back: quadrant q of the wave = 8 rows x 128 B
             {

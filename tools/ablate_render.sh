@@ -9,7 +9,7 @@ cd audio-motion-avatar_amd/csrc
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-slp-vectorize"
 for n in 3 5 7; do
   /opt/rocm/bin/hipcc $FLAGS -DAMAV_ABLATE=$n -c rasterizer.hip -o /tmp/amav_ablate/rasterizer_$n.o || exit 1
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC api.o /tmp/amav_ablate/rasterizer_$n.o lbs.o triplane.o attention.o frames.o splat.o cloud.o -o /tmp/amav_ablate/libamav_$n.so || exit 1
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC api.o /tmp/amav_ablate/rasterizer_$n.o lbs.o triplane.o attention.o frames.o splat.o cloud.o gemm.o -L/opt/rocm/lib -lhipblaslt -o /tmp/amav_ablate/libamav_$n.so || exit 1
 done
 cd ../..
 B="python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-full-path --no-refiner --no-extra-configs"

@@ -12,7 +12,8 @@ from audio_motion_avatar_amd.config import RendererConfig  # noqa: E402
 from audio_motion_avatar_amd.renderer import Renderer, render_batch  # noqa: E402
 from audio_motion_avatar_amd.synthetic import init_random_heads, make_render_inputs  # noqa: E402
 
-F = int(sys.argv[1]) if len(sys.argv) > 1 else 250
+F = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 250
+DETAIL = "--detail" in sys.argv  # the library was built with -DAMAV_STAMP_DETAIL (tools/stamp_detail.sh)
 cfg = RendererConfig(image_size=(512, 512), subdivide_steps=0, predict_smplx_params=False, device="cuda")
 r = init_random_heads(Renderer(cfg).eval())
 tokens, smpl, cam = make_render_inputs(F, cfg, seed=42)
@@ -35,6 +36,27 @@ t0 = s[ne, 0].min()
 span = (s[ne, 4].max() - t0) * US
 print(f"tiles {len(n)}, nonempty {ne.sum()}, mean n (nonempty) {n[ne].mean():.1f}, max n {n.max()}, kernel span {span:.1f} us")
 sn = s[ne]
+if DETAIL:
+    tile = (sn[:, 4] - sn[:, 0]) * US
+    asm_t = sn[:, 1] * US
+    prep_t = (sn[:, 2] >> 48) * US
+    fill_t = ((sn[:, 2] >> 32) & 0xffff) * US
+    stage_t = ((sn[:, 2] >> 16) & 0xffff) * US
+    own_t = (sn[:, 2] & 0xffff) * US
+    store_t = (sn[:, 4] - sn[:, 3]) * US
+    rest = tile - asm_t - prep_t - fill_t - store_t - stage_t - own_t
+    waves = 4096
+    print(f"per wave (/{waves}): in tiles {tile.sum() / waves:7.1f} us = blend loops {asm_t.sum() / waves:6.1f} + next tile's sort and gather issue "
+          f"{prep_t.sum() / waves:6.1f} + background stores {fill_t.sum() / waves:6.1f} + tile store {store_t.sum() / waves:6.1f} + "
+          f"staging (wait for records, masks, lists) {stage_t.sum() / waves:6.1f} + own sort (unprepared tiles) {own_t.sum() / waves:6.1f} + "
+          f"rest {rest.sum() / waves:6.1f}; between tiles {span - tile.sum() / waves:6.1f}")
+    nn = sn[:, 5]
+    for lo, hi in ((1, 32), (32, 64), (64, 128), (128, 256), (256, 512), (512, 10**9)):
+        m = (nn >= lo) & (nn < hi)
+        if m.any():
+            print(f"  n in [{lo},{hi}): {m.sum():6d} tiles  tile {tile[m].mean():7.2f} us  blend {asm_t[m].mean():7.2f}  prep {prep_t[m].mean():6.2f}  "
+                  f"fill {fill_t[m].mean():6.2f}  store {store_t[m].mean():5.2f}  stage {stage_t[m].mean():6.2f}  own {own_t[m].mean():6.2f}  rest {rest[m].mean():7.2f}   blend/gaussian {asm_t[m].sum() / nn[m].sum() * 1e3:6.1f} ns")
+    sys.exit(0)
 ph = [(sn[:, i + 1] - sn[:, i]) * US for i in range(4)]
 for nm, d in zip(["read ranges", "load+sort", "blend", "store"], ph):
     print(f"  {nm:12s} wave-time total {d.sum() / 1e3:8.2f} ms   mean {d.mean():7.2f} us   p99 {np.percentile(d, 99):7.2f} us")
