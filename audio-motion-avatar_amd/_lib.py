@@ -53,6 +53,15 @@ class BodyTables(ctypes.Structure):
     ]
 
 
+class PoseParts(ctypes.Structure):
+    _fields_ = [
+        ("num_pose_parts", ctypes.c_int32), ("num_coeff_parts", ctypes.c_int32),
+        ("pose", ctypes.c_void_p * 8), ("pose_joints", ctypes.c_int32 * 8), ("pose_stride", ctypes.c_int64 * 8),
+        ("pose_mean", ctypes.c_void_p),
+        ("coeff", ctypes.c_void_p * 4), ("coeff_count", ctypes.c_int32 * 4), ("coeff_stride", ctypes.c_int64 * 4),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/amav.h declares
 SIGNATURES = {
     "amav_version": (ctypes.c_char_p, []),
@@ -146,6 +155,8 @@ SIGNATURES = {
                                                     ctypes.c_void_p]),
     "amav_lbs_forward": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(BodyTables), c_float_p, c_float_p, c_float_p,
                                         c_float_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "amav_lbs_forward_parts": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(BodyTables), ctypes.POINTER(PoseParts), c_float_p,
+                                              c_float_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "amav_points_gather": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_float_p, ctypes.c_void_p,
                                           c_float_p, ctypes.c_void_p]),
     "amav_triplane_project": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_float_p, ctypes.c_int64,

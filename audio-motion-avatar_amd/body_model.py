@@ -11,7 +11,6 @@ arrays when a path is given.  All arithmetic on vertices happens in the HIP kern
 prepares immutable tables once, on the host.
 """
 import os
-from types import SimpleNamespace
 
 import numpy as np
 import torch
@@ -241,6 +240,18 @@ def build_subdivision_table(faces: np.ndarray, num_verts: int, levels: int) -> n
     return np.concatenate([keep, mids], axis=0).astype(np.int32)
 
 
+class _BodyOutput:
+    """`.vertices`, and `.full_pose` (smplx's output field; nothing on the path reads it) assembled on first use."""
+
+    def __init__(self, vertices, make_full_pose):
+        self.vertices = vertices
+        self._make_full_pose = make_full_pose
+
+    @property
+    def full_pose(self):
+        return self._make_full_pose()
+
+
 class BodyModel(torch.nn.Module):
     """Drop-in for the `smplx.SMPLX` object the reference builds (renderer.py:206-225)."""
 
@@ -342,9 +353,17 @@ class BodyModel(torch.nn.Module):
 
     def forward(self, global_orient, body_pose, betas, left_hand_pose, right_hand_pose, jaw_pose, leye_pose,
                 reye_pose, expression, **unused):
-        """Same keyword call as renderer.py:261-272; returns an object with `.vertices` [B,V,3]."""
-        fp = self.full_pose(global_orient, body_pose, jaw_pose, leye_pose, reye_pose, left_hand_pose,
-                            right_hand_pose).float()
-        coeffs = torch.cat([betas.reshape(fp.shape[0], -1), expression.reshape(fp.shape[0], -1)], dim=1).float()
-        verts = ops.lbs_forward(self.device_tables(), fp, coeffs)
-        return SimpleNamespace(vertices=verts, full_pose=fp)
+        """Same keyword call as renderer.py:261-272; returns an object with `.vertices` [B,V,3] (and, computed on
+        demand, smplx's `.full_pose`).  float32 arguments go to the joint-chain kernel as they are (it concatenates on
+        load and adds pose_mean: smplx's torch.cat + add + torch.cat were three launches); other dtypes are assembled
+        with torch first, in their own dtype as smplx does."""
+        B = global_orient.shape[0]
+        pose = [global_orient.reshape(B, 3), body_pose.reshape(B, 63), jaw_pose.reshape(B, 3), leye_pose.reshape(B, 3),
+                reye_pose.reshape(B, 3), left_hand_pose.reshape(B, 45), right_hand_pose.reshape(B, 45)]
+        coeff = [betas.reshape(B, -1), expression.reshape(B, -1)]
+        if all(p.dtype == torch.float32 and (p.shape[1] == 1 or p.stride(1) == 1) for p in pose + coeff):
+            verts = ops.lbs_forward_parts(self.device_tables(), pose, coeff, pose_mean=self.pose_mean)
+        else:
+            fp = (torch.cat(pose, dim=1) + self.pose_mean).float()
+            verts = ops.lbs_forward(self.device_tables(), fp, torch.cat(coeff, dim=1).float())
+        return _BodyOutput(verts, lambda: (torch.cat(pose, dim=1) + self.pose_mean).float())

@@ -40,17 +40,65 @@ struct Tables {
     const void *blend_split;  // fp16 x 2 form of `blend` (amav_lbs_prepare_blend_split) or NULL
 };
 
-__global__ __launch_bounds__(64) void joint_chain_kernel(Tables t, int F, int Fpad, const float *__restrict__ full_pose,
-                                                        const float *__restrict__ coeffs, float *__restrict__ featT,
-                                                        float *__restrict__ A_out) {
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr size_t kSplitHeaderBytes = 256;  // [0]: float, largest |table entry|; [1]: int, the table's scale exponent
+
+__device__ __forceinline__ int f16_scale_exp(float amax) {
+    if (!(amax > 0.f)) return 0;
+    return max(-100, min(100, 14 - ilogbf(amax)));
+}
+__device__ __forceinline__ void split2(float x, _Float16 &a, _Float16 &b) {
+    a = (_Float16)x;
+    b = (_Float16)__builtin_fmaf((float)a, -1.0f, x);
+}
+static inline int k16_of(int KB) { return (KB + 31) / 32 * 32; }  // table rows padded to whole 32-row chunks
+
+constexpr int kMaxFeatures = 64 + (kMaxJoints - 1) * 9;  // KB <= num_coeffs + (J - 1) * 9
+
+// Where the pose and the shape / expression coefficients of a frame come from: the keyword arguments of the SMPL-X
+// call as the caller holds them (global_orient, body_pose, jaw_pose, ... / betas, expression: renderer.py:261-272),
+// concatenated on load -- smplx's torch.cat + `full_pose += pose_mean` + torch.cat were three launches of ~16 us each
+// in front of a 12 us kernel.  One part each = an assembled full_pose / coefficient matrix.
+struct PoseSource {
+    int nparts, ncparts;
+    int first[8], cfirst[4];        // first joint / coefficient of every part
+    const float *part[8], *cpart[4];
+    long long stride[8], cstride[4];  // floats between frames
+    const float *mean;              // [J*3] added to the concatenated pose, or NULL
+};
+
+// One 64-lane block per frame (kSplit: per padded frame).  kSplit = the feature row of the frame goes straight into the
+// fp16 x 2 operand layout of skin_f16_kernel (featH, fscale) instead of the fp32 matrix featT.
+template <bool kSplit>
+__global__ __launch_bounds__(64) void joint_chain_kernel(Tables t, int F, int Fpad, PoseSource src, float *__restrict__ featT,
+                                                        float *__restrict__ A_out, int K16, const unsigned *__restrict__ hdr,
+                                                        _Float16 *__restrict__ featH, float *__restrict__ fscale) {
     __shared__ float G[kMaxJoints][12];
     __shared__ float coef[64];
     __shared__ int depth_s[kMaxJoints];
+    __shared__ float feat_s[kSplit ? kMaxFeatures : 1];
     const int f = blockIdx.x, j = threadIdx.x;
+    const bool live = f < F;  // kSplit only: padded frames carry zero features and scale 1
+    auto put_feature = [&](int k, float v) {
+        if (kSplit)
+            feat_s[k] = v;
+        else
+            featT[(size_t)k * Fpad + f] = v;
+    };
+    if (live) {
     if (j < t.NC) {
-        const float c = coeffs[(size_t)f * t.NC + j];
+        const float *base = src.cpart[0];
+        long long st = src.cstride[0];
+        int fj = 0;
+#pragma unroll
+        for (int q = 1; q < 4; ++q) {
+            const bool in = q < src.ncparts && j >= src.cfirst[q];
+            base = in ? src.cpart[q] : base, st = in ? src.cstride[q] : st, fj = in ? src.cfirst[q] : fj;
+        }
+        const float c = base[(size_t)f * st + (j - fj)];
         coef[j] = c;
-        featT[(size_t)j * Fpad + f] = c;
+        put_feature(j, c);
     }
     __syncthreads();
     float R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
@@ -58,8 +106,17 @@ __global__ __launch_bounds__(64) void joint_chain_kernel(Tables t, int F, int Fp
     int parent = -1, depth = 0;
     if (j < t.J) {
         // Rodrigues, smplx.lbs.batch_rodrigues: eps is added to every component before the norm
-        const float rx = full_pose[(size_t)f * t.J * 3 + j * 3], ry = full_pose[(size_t)f * t.J * 3 + j * 3 + 1],
-                    rz = full_pose[(size_t)f * t.J * 3 + j * 3 + 2];
+        const float *base = src.part[0];
+        long long st = src.stride[0];
+        int fj = 0;
+#pragma unroll
+        for (int q = 1; q < 8; ++q) {
+            const bool in = q < src.nparts && j >= src.first[q];
+            base = in ? src.part[q] : base, st = in ? src.stride[q] : st, fj = in ? src.first[q] : fj;
+        }
+        base += (size_t)f * st + (j - fj) * 3;
+        float rx = base[0], ry = base[1], rz = base[2];
+        if (src.mean) rx += src.mean[j * 3], ry += src.mean[j * 3 + 1], rz += src.mean[j * 3 + 2];
         const float ex = rx + 1e-8f, ey = ry + 1e-8f, ez = rz + 1e-8f;
         const float angle = sqrtf(ex * ex + ey * ey + ez * ez);
         const float kx = rx / angle, ky = ry / angle, kz = rz / angle;
@@ -75,9 +132,8 @@ __global__ __launch_bounds__(64) void joint_chain_kernel(Tables t, int F, int Fp
         R[7] = s * kx + c1 * (ky * kz);
         R[8] = 1.0f + c1 * (-ky * ky - kx * kx);
         if (j >= 1) {
-            float *dst = featT + (size_t)(t.NC + (j - 1) * 9) * Fpad + f;
 #pragma unroll
-            for (int e = 0; e < 9; ++e) dst[(size_t)e * Fpad] = R[e] - ((e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f);
+            for (int e = 0; e < 9; ++e) put_feature(t.NC + (j - 1) * 9 + e, R[e] - ((e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f));
         }
         // joint location: J = J_regressor (v_template + dirs c) = j_template + j_dirs c
 #pragma unroll
@@ -136,6 +192,35 @@ __global__ __launch_bounds__(64) void joint_chain_kernel(Tables t, int F, int Fp
             dst[r * 4 + 1] = Gj[r * 4 + 1];
             dst[r * 4 + 2] = Gj[r * 4 + 2];
             dst[r * 4 + 3] = Gj[r * 4 + 3] - (Gj[r * 4] * Jp[0] + Gj[r * 4 + 1] * Jp[1] + Gj[r * 4 + 2] * Jp[2]);
+        }
+    }
+    }  // live
+    if (kSplit) {
+        // the frame's largest |feature| -> its scale exponent; features -> featH [part][k / 8][Fpad][8] fp16 (lane
+        // (frame, hh) of the skin kernel reads 16 contiguous bytes per part and k-step), fscale[frame] =
+        // 2^-(e_frame + e_table) for the epilogue.  Rows KB..K16-1 are zero.  (feat_s is complete: barriers above.)
+        const int KB = t.KB;
+        float m = 0.f;
+        for (int k = j; k < KB; k += 64) m = fmaxf(m, live ? fabsf(feat_s[k]) : 0.f);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        const int e = f16_scale_exp(m);
+        const float scale = ldexpf(1.0f, e);
+        if (j == 0) fscale[f] = ldexpf(1.0f, -(e + reinterpret_cast<const int *>(hdr)[1]));
+        const size_t part = (size_t)(K16 / 8) * Fpad * 8;
+        for (int k8 = j; k8 < K16 / 8; k8 += 64) {
+            f16x8 p1, p2;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int k = 8 * k8 + i;
+                const float x = (live && k < KB) ? feat_s[k] : 0.f;
+                _Float16 a, b;
+                split2(x * scale, a, b);
+                p1[i] = a, p2[i] = b;
+            }
+            _Float16 *dst = featH + ((size_t)k8 * Fpad + f) * 8;
+            *reinterpret_cast<f16x8 *>(dst) = p1;
+            *reinterpret_cast<f16x8 *>(dst + part) = p2;
         }
     }
 }
@@ -357,22 +442,9 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 3) void skin_mfma_kernel(Tables t,
 //   x 2^e = h1 + h2 (two fp16 parts, 22 bits),   a b = (a1 b1 + a1 b2 + a2 b1) 2^-(ea + eb)   to 2^-22,
 // three v_mfma_f32_32x32x16_f16 per fp32 product, each 8 x the k depth of the fp32 MFMA at half its cycles.
 // Scaling (exact powers of two): the table by ONE exponent from its largest magnitude (static, prepared once); every
-// frame's feature column by its own exponent from that frame's largest feature (split_features_kernel), undone per
+// frame's feature column by its own exponent from that frame's largest feature (joint_chain_kernel<true>), undone per
 // accumulator row in the epilogue.  Both put the largest magnitude in [2^14, 2^15): nothing overflows, and entries
 // down to 2^-17 of the largest keep all 22 bits (smaller ones an absolute error below 2^-39 of it).
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-
-constexpr size_t kSplitHeaderBytes = 256;  // [0]: float, largest |table entry|; [1]: int, the table's scale exponent
-
-__device__ __forceinline__ int f16_scale_exp(float amax) {
-    if (!(amax > 0.f)) return 0;
-    return max(-100, min(100, 14 - ilogbf(amax)));
-}
-__device__ __forceinline__ void split2(float x, _Float16 &a, _Float16 &b) {
-    a = (_Float16)x;
-    b = (_Float16)__builtin_fmaf((float)a, -1.0f, x);
-}
-static inline int k16_of(int KB) { return (KB + 31) / 32 * 32; }  // table rows padded to whole 32-row chunks
 
 __global__ __launch_bounds__(256) void table_absmax_kernel(const float4 *__restrict__ blend4, long long n4,
                                                            unsigned *__restrict__ hdr) {
@@ -415,38 +487,6 @@ __global__ __launch_bounds__(256) void table_split_kernel(const float *__restric
     _Float16 *dst = out + (((tile * steps + step) * 2) * 3 + comp) * 512 + hh * 256 + c * 8;
     *reinterpret_cast<f16x8 *>(dst) = p1;
     *reinterpret_cast<f16x8 *>(dst + 3 * 512) = p2;
-}
-
-// one 64-lane block per frame: the frame's largest |feature| -> its scale exponent; featT [k][Fpad] fp32 ->
-// featH [part][k / 8][Fpad][8] fp16 (lane (frame, hh) of the skin kernel reads 16 contiguous bytes per part and k-step)
-// and fscale[frame] = 2^-(e_frame + e_table) for the epilogue.  Rows KB..K16-1 are zero.
-__global__ __launch_bounds__(64) void split_features_kernel(int KB, int K16, int F, int Fpad, const float *__restrict__ featT,
-                                                           const unsigned *__restrict__ hdr, _Float16 *__restrict__ featH,
-                                                           float *__restrict__ fscale) {
-    const int f = blockIdx.x, lane = threadIdx.x;
-    const bool live = f < F;  // padded frames: zero features, scale 1
-    float m = 0.f;
-    for (int k = lane; k < KB; k += 64) m = fmaxf(m, live ? fabsf(featT[(size_t)k * Fpad + f]) : 0.f);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    const int e = f16_scale_exp(m);
-    const float scale = ldexpf(1.0f, e);
-    if (lane == 0) fscale[f] = ldexpf(1.0f, -(e + reinterpret_cast<const int *>(hdr)[1]));
-    const size_t part = (size_t)(K16 / 8) * Fpad * 8;
-    for (int k8 = lane; k8 < K16 / 8; k8 += 64) {
-        f16x8 p1, p2;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = 8 * k8 + j;
-            const float x = (live && k < KB) ? featT[(size_t)k * Fpad + f] : 0.f;
-            _Float16 a, b;
-            split2(x * scale, a, b);
-            p1[j] = a, p2[j] = b;
-        }
-        _Float16 *dst = featH + ((size_t)k8 * Fpad + f) * 8;
-        *reinterpret_cast<f16x8 *>(dst) = p1;
-        *reinterpret_cast<f16x8 *>(dst + part) = p2;
-    }
 }
 
 // Same decomposition as skin_mfma_kernel (block = 4 waves = 128 frames x one 32-vertex tile, the tile's table slab
@@ -688,12 +728,37 @@ extern "C" size_t amav_lbs_workspace_bytes(int F, const amav_body_tables *t) {
     return lbs_ws(F, t, nullptr, nullptr, nullptr);
 }
 
-extern "C" int amav_lbs_forward(int F, const amav_body_tables *tb, const float *full_pose, const float *coeffs,
-                                float *out_vertices, float *out_A, void *workspace, size_t workspace_bytes,
-                                void *stream_) {
+extern "C" int amav_lbs_forward_parts(int F, const amav_body_tables *tb, const amav_pose_parts *pp, float *out_vertices,
+                                      float *out_A, void *workspace, size_t workspace_bytes, void *stream_) {
     AMAV_REQUIRE(F > 0, "amav_lbs_forward: F=%d", F);
     if (int rc = validate_tables(tb, "amav_lbs_forward")) return rc;
-    AMAV_REQUIRE(full_pose && coeffs && out_vertices && workspace, "amav_lbs_forward: NULL pointer");
+    AMAV_REQUIRE(pp && out_vertices && workspace, "amav_lbs_forward: NULL pointer");
+    PoseSource src;
+    {
+        AMAV_REQUIRE(pp->num_pose_parts >= 1 && pp->num_pose_parts <= 8 && pp->num_coeff_parts >= 1 && pp->num_coeff_parts <= 4,
+                     "amav_lbs_forward: %d pose parts (1..8), %d coefficient parts (1..4)", pp->num_pose_parts, pp->num_coeff_parts);
+        int joints = 0, ncoef = 0;
+        for (int q = 0; q < 8; ++q) {
+            const bool used = q < pp->num_pose_parts;
+            AMAV_REQUIRE(!used || (pp->pose[q] && pp->pose_joints[q] > 0 && pp->pose_stride[q] >= 3ll * pp->pose_joints[q]),
+                         "amav_lbs_forward: pose part %d: NULL, no joints, or frame stride %lld < 3 * %d", q,
+                         (long long)pp->pose_stride[q], pp->pose_joints[q]);
+            src.first[q] = joints, src.part[q] = used ? pp->pose[q] : nullptr, src.stride[q] = used ? pp->pose_stride[q] : 0;
+            if (used) joints += pp->pose_joints[q];
+        }
+        for (int q = 0; q < 4; ++q) {
+            const bool used = q < pp->num_coeff_parts;
+            AMAV_REQUIRE(!used || (pp->coeff[q] && pp->coeff_count[q] > 0 && pp->coeff_stride[q] >= pp->coeff_count[q]),
+                         "amav_lbs_forward: coefficient part %d: NULL, empty, or frame stride %lld < %d", q,
+                         (long long)pp->coeff_stride[q], pp->coeff_count[q]);
+            src.cfirst[q] = ncoef, src.cpart[q] = used ? pp->coeff[q] : nullptr, src.cstride[q] = used ? pp->coeff_stride[q] : 0;
+            if (used) ncoef += pp->coeff_count[q];
+        }
+        AMAV_REQUIRE(joints == tb->num_joints && ncoef == tb->num_coeffs,
+                     "amav_lbs_forward: the parts hold %d joints / %d coefficients, the tables %d / %d", joints, ncoef,
+                     tb->num_joints, tb->num_coeffs);
+        src.nparts = pp->num_pose_parts, src.ncparts = pp->num_coeff_parts, src.mean = pp->pose_mean;
+    }
     float *featT = nullptr, *A = nullptr, *fscale = nullptr;
     _Float16 *featH = nullptr;
     const size_t need = lbs_ws(F, tb, &featT, &A, workspace, &featH, &fscale);
@@ -707,25 +772,27 @@ extern "C" int amav_lbs_forward(int F, const amav_body_tables *tb, const float *
     const int FT = frame_tile(F, t.KB);
     const int Fpad = frame_pad(F, FT);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    float *A_dst = out_A ? out_A : A;
+    if (lbs_use_split(tb, FT)) {
+        // product path: the chain kernel writes the fp16 x 2 feature operand itself (padded frames included)
+        const int K16 = k16_of(t.KB);
+        const int ntiles = (t.V + 31) / 32, ngroups = (Fpad / 32 + kMfmaWaves - 1) / kMfmaWaves;
+        const unsigned mgrid = (unsigned)(((ntiles + 7) / 8) * 8 * ngroups);
+        joint_chain_kernel<true><<<Fpad, 64, 0, stream>>>(t, F, Fpad, src, nullptr, A_dst, K16,
+                                                          static_cast<const unsigned *>(t.blend_split), featH, fscale);
+        skin_f16_kernel<<<mgrid, 64 * kMfmaWaves, 0, stream>>>(t, F, Fpad, ntiles, K16, featH, fscale, A_dst, out_vertices);
+        return check_launch("amav_lbs_forward");
+    }
     // padded frame columns of featT must be finite (they feed FMAs whose results are discarded), and the MFMA path
     // reads kMfmaKPad zero rows past the table
     const size_t feat_rows = (size_t)t.KB + (FT ? 0 : kMfmaKPad);
     if ((Fpad != F || FT == 0) && zero_async(featT, feat_rows * Fpad * sizeof(float), stream) != hipSuccess)
         return fail(AMAV_ERR_LAUNCH, "amav_lbs_forward: padding clear failed");
-    float *A_dst = out_A ? out_A : A;
-    joint_chain_kernel<<<F, 64, 0, stream>>>(t, F, Fpad, full_pose, coeffs, featT, A_dst);
+    joint_chain_kernel<false><<<F, 64, 0, stream>>>(t, F, Fpad, src, featT, A_dst, 0, nullptr, nullptr, nullptr);
     if (FT == 0) {
         const int ntiles = (t.V + 31) / 32, ngroups = (Fpad / 32 + kMfmaWaves - 1) / kMfmaWaves;
         const unsigned mgrid = (unsigned)(((ntiles + 7) / 8) * 8 * ngroups);
-        if (lbs_use_split(tb, FT)) {
-            const int K16 = k16_of(t.KB);
-            split_features_kernel<<<Fpad, 64, 0, stream>>>(t.KB, K16, F, Fpad, featT,
-                                                          static_cast<const unsigned *>(t.blend_split), featH, fscale);
-            skin_f16_kernel<<<mgrid, 64 * kMfmaWaves, 0, stream>>>(t, F, Fpad, ntiles, K16, featH, fscale, A_dst,
-                                                                   out_vertices);
-        } else {
-            skin_mfma_kernel<<<mgrid, 64 * kMfmaWaves, 0, stream>>>(t, F, Fpad, ntiles, featT, A_dst, out_vertices);
-        }
+        skin_mfma_kernel<<<mgrid, 64 * kMfmaWaves, 0, stream>>>(t, F, Fpad, ntiles, featT, A_dst, out_vertices);
         return check_launch("amav_lbs_forward");
     }
     const int nchunks = (t.V + 255) / 256;
@@ -740,6 +807,17 @@ extern "C" int amav_lbs_forward(int F, const amav_body_tables *tb, const float *
     else
         skin_kernel<16><<<grid, 256, lds, stream>>>(t, F, Fpad, nchunks, featT, A_dst, out_vertices);
     return check_launch("amav_lbs_forward");
+}
+
+extern "C" int amav_lbs_forward(int F, const amav_body_tables *tb, const float *full_pose, const float *coeffs,
+                                float *out_vertices, float *out_A, void *workspace, size_t workspace_bytes,
+                                void *stream) {
+    AMAV_REQUIRE(tb != nullptr, "amav_lbs_forward: NULL tables");
+    AMAV_REQUIRE(full_pose && coeffs, "amav_lbs_forward: NULL pointer");
+    amav_pose_parts pp = {};
+    pp.num_pose_parts = 1, pp.pose[0] = full_pose, pp.pose_joints[0] = tb->num_joints, pp.pose_stride[0] = 3ll * tb->num_joints;
+    pp.num_coeff_parts = 1, pp.coeff[0] = coeffs, pp.coeff_count[0] = tb->num_coeffs, pp.coeff_stride[0] = tb->num_coeffs;
+    return amav_lbs_forward_parts(F, tb, &pp, out_vertices, out_A, workspace, workspace_bytes, stream);
 }
 
 extern "C" int amav_points_gather(int F, int V, int N, const float *vertices, const int32_t *idx, float *out,

@@ -7,7 +7,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import AmavError, Attr, BodyTables, RasterArgs, check
+from ._lib import AmavError, Attr, BodyTables, PoseParts, RasterArgs, check
 
 SCALE_BIAS = 3.9    # src/models/renderer.py:428
 OPACITY_BIAS = 0.0  # src/models/renderer.py:429
@@ -386,6 +386,59 @@ def lbs_forward(tables: dict, full_pose, coeffs, want_transforms=False):
     check(_lib.lib().amav_lbs_forward(F, ctypes.byref(ts), full_pose.data_ptr(), coeffs.data_ptr(), verts.data_ptr(),
                                       A.data_ptr() if A is not None else None, ws.data_ptr(), nbytes, _stream()),
           "amav_lbs_forward")
+    return (verts, A) if want_transforms else verts
+
+
+def lbs_forward_parts(tables: dict, pose_parts, coeff_parts, pose_mean=None, want_transforms=False):
+    """lbs_forward with the pose / coefficients as the SMPL-X call's keyword arguments hold them (renderer.py:261-272):
+    `pose_parts` = float32 tensors [F, joints_p * 3] (rows may be strided, elements contiguous) concatenated in order,
+    `coeff_parts` likewise (betas, expression), `pose_mean` [J*3] is added to the concatenated pose (smplx's
+    full_pose += pose_mean).  No torch.cat / add launches: the joint-chain kernel reads the parts."""
+    ts = body_tables_struct(tables)
+    F = int(pose_parts[0].shape[0])
+    pp = PoseParts()
+    keep = []
+
+    def rows(tt, name):
+        _need(tt, name)
+        if tt.dtype != torch.float32 or tt.dim() != 2 or tt.shape[0] != F or (tt.shape[1] > 1 and tt.stride(1) != 1):
+            raise AmavError(f"lbs: {name} must be float32 [F={F}, n] with contiguous rows, got {tuple(tt.shape)} {tt.dtype}")
+        if F > 1 and tt.stride(0) < tt.shape[1]:
+            tt = tt.contiguous()  # broadcast rows
+        keep.append(tt)
+        return tt
+
+    if not 1 <= len(pose_parts) <= 8 or not 1 <= len(coeff_parts) <= 4:
+        raise AmavError(f"lbs: {len(pose_parts)} pose parts (1..8), {len(coeff_parts)} coefficient parts (1..4)")
+    pp.num_pose_parts, pp.num_coeff_parts = len(pose_parts), len(coeff_parts)
+    for q, part in enumerate(pose_parts):
+        part = rows(part, f"pose part {q}")
+        if part.shape[1] % 3:
+            raise AmavError(f"lbs: pose part {q} has {part.shape[1]} columns (not axis-angle triples)")
+        pp.pose[q], pp.pose_joints[q] = part.data_ptr(), part.shape[1] // 3
+        pp.pose_stride[q] = part.stride(0) if F > 1 else part.shape[1]
+    for q, part in enumerate(coeff_parts):
+        part = rows(part, f"coefficient part {q}")
+        pp.coeff[q], pp.coeff_count[q] = part.data_ptr(), part.shape[1]
+        pp.coeff_stride[q] = part.stride(0) if F > 1 else part.shape[1]
+    if sum(pp.pose_joints[q] for q in range(len(pose_parts))) != ts.num_joints or \
+            sum(pp.coeff_count[q] for q in range(len(coeff_parts))) != ts.num_coeffs:
+        raise AmavError(f"lbs: the parts do not add up to J={ts.num_joints} joints / {ts.num_coeffs} coefficients")
+    if pose_mean is not None:
+        pose_mean = _contig(pose_mean.reshape(-1), "pose_mean")
+        if pose_mean.numel() != ts.num_joints * 3:
+            raise AmavError(f"lbs: pose_mean has {pose_mean.numel()} entries, expected {ts.num_joints * 3}")
+        pp.pose_mean = pose_mean.data_ptr()
+    dev = keep[0].device
+    nbytes = _lib.lib().amav_lbs_workspace_bytes(F, ctypes.byref(ts))
+    if nbytes == 0:
+        raise AmavError("amav_lbs_workspace_bytes rejected the tables: " + _lib.lib().amav_last_error().decode())
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    verts = torch.empty(F, ts.num_verts, 3, device=dev)
+    A = torch.empty(F, ts.num_joints, 12, device=dev) if want_transforms else None
+    check(_lib.lib().amav_lbs_forward_parts(F, ctypes.byref(ts), ctypes.byref(pp), verts.data_ptr(),
+                                            A.data_ptr() if A is not None else None, ws.data_ptr(), nbytes, _stream()),
+          "amav_lbs_forward_parts")
     return (verts, A) if want_transforms else verts
 
 

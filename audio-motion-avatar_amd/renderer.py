@@ -17,6 +17,8 @@ Changed on purpose (MI355X-first):
     TriplaneUpsampler through library convolutions (torch / MIOpen), then the same fused decode.
 There is no CPU path: every tensor must be on the HIP device.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -196,9 +198,20 @@ class Renderer(nn.Module):
         """
         F = triplane_tokens.shape[0]
         w_plane, w_point = self._head_weights()
-        proj = ops.triplane_project(triplane_tokens, w_plane, self._plane_resolution(triplane_tokens))
-        side_result = side_work() if side_work is not None else None
-        vertices = self._posed_vertices(smpl_params)
+        if os.environ.get("AMAV_SIDE_LBS") == "1" and not hasattr(self, "point_encoder"):
+            cur = torch.cuda.current_stream()
+            if getattr(self, "_lbs_stream", None) is None:
+                self._lbs_stream = torch.cuda.Stream(device=triplane_tokens.device)
+            self._lbs_stream.wait_stream(cur)
+            with torch.cuda.stream(self._lbs_stream):
+                side_result = side_work() if side_work is not None else None
+                vertices = self._posed_vertices(smpl_params)
+            proj = ops.triplane_project(triplane_tokens, w_plane, self._plane_resolution(triplane_tokens))
+            cur.wait_stream(self._lbs_stream)
+        else:
+            proj = ops.triplane_project(triplane_tokens, w_plane, self._plane_resolution(triplane_tokens))
+            side_result = side_work() if side_work is not None else None
+            vertices = self._posed_vertices(smpl_params)
         transl = smpl_params["transl"].reshape(F, 3).float()
         if hasattr(self, "point_encoder"):
             if self.cfg.densify_smplx_verts:

@@ -212,6 +212,27 @@ int amav_lbs_forward(int num_frames, const amav_body_tables *tables, const float
                      const float *coeffs_dev, float *out_vertices_dev, float *out_joint_transforms_dev,
                      void *workspace, size_t workspace_bytes, void *stream);
 
+/* The same with the pose and the coefficients as the caller of the SMPL-X layer holds them -- the keyword arguments of
+ * renderer.py:261-272 (global_orient, body_pose, jaw_pose, leye_pose, reye_pose, left_hand_pose, right_hand_pose / betas,
+ * expression) -- concatenated in the given order as the first kernel loads them, plus smplx's `full_pose += pose_mean`:
+ * what smplx does with torch.cat / add / torch.cat (three launches) in front of the joint chain.  Part p holds
+ * pose_joints[p] axis-angle triples per frame, pose_stride[p] floats apart between frames; the joint counts must add up
+ * to tables->num_joints and the coefficient counts to tables->num_coeffs.  pose_mean [J*3] may be NULL. */
+typedef struct amav_pose_parts {
+    int32_t num_pose_parts;  /* 1..8 */
+    int32_t num_coeff_parts; /* 1..4 */
+    const float *pose[8];
+    int32_t pose_joints[8];
+    int64_t pose_stride[8];
+    const float *pose_mean;
+    const float *coeff[4];
+    int32_t coeff_count[4];
+    int64_t coeff_stride[4];
+} amav_pose_parts;
+int amav_lbs_forward_parts(int num_frames, const amav_body_tables *tables, const amav_pose_parts *parts,
+                           float *out_vertices_dev, float *out_joint_transforms_dev, void *workspace,
+                           size_t workspace_bytes, void *stream);
+
 /* Densify + subset of the posed vertices (src/models/renderer.py:276-288: pytorch3d SubdivideMeshes applied to the
  * posed mesh once or twice, then a vertex subset) as one baked table of 4 base-vertex ids per output point:
  *   point n = 1/2 * ( 1/2 * (v[a0] + v[b0]) + 1/2 * (v[a1] + v[b1]) ),   idx[n] = (a0, b0, a1, b1)

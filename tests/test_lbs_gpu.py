@@ -117,6 +117,38 @@ def test_split_product_kernel_is_reproducible():
         assert torch.equal(ops.lbs_forward(tables, pose.cuda(), coeffs.cuda()), first)
 
 
+@pytest.mark.parametrize("F", [1, 6, 40, 150])  # FMA kernels, fp32 / fp16 x 2 MFMA kernels (the latter fuses the split)
+def test_pose_parts_entry_is_bit_identical_to_the_assembled_pose(F):
+    """amav_lbs_forward_parts concatenates the SMPL-X keyword arguments (renderer.py:261-272) and adds pose_mean while
+    loading: same fp32 sums as torch.cat + add, so the same vertices and joint transforms bit for bit -- with rows that
+    are views into wider tensors (strided), as Renderer hands them over."""
+    from audio_motion_avatar_amd import ops
+
+    pose, coeffs = random_pose(500 + F, F, scale=0.3)
+    mean = torch.zeros(165)
+    mean[75:165] = torch.randn(90, generator=torch.Generator().manual_seed(3)) * 0.2
+    tables = body().device_tables()
+    fp = (pose + mean).cuda()
+    want_v, want_A = ops.lbs_forward(tables, fp, coeffs.cuda(), want_transforms=True)
+    wide = torch.zeros(F, 200).cuda()
+    wide[:, 10:175] = pose.cuda()
+    cuts = [0, 3, 66, 69, 72, 75, 120, 165]
+    parts = [wide[:, 10 + a:10 + b] for a, b in zip(cuts[:-1], cuts[1:])]
+    assert F == 1 or not parts[1].is_contiguous()
+    cw = coeffs.cuda()
+    got_v, got_A = ops.lbs_forward_parts(tables, parts, [cw[:, :10], cw[:, 10:]], pose_mean=mean.cuda(), want_transforms=True)
+    assert torch.equal(got_v, want_v) and torch.equal(got_A, want_A)
+    # one part each = the assembled entry
+    v1 = ops.lbs_forward_parts(tables, [fp], [cw])
+    assert torch.equal(v1, want_v)
+    with pytest.raises(ops.AmavError):
+        ops.lbs_forward_parts(tables, parts[:-1], [cw])          # joints do not add up
+    with pytest.raises(ops.AmavError):
+        ops.lbs_forward_parts(tables, parts, [cw[:, :10]])        # coefficients do not add up
+    with pytest.raises(ops.AmavError):
+        ops.lbs_forward_parts(tables, [p.double() for p in parts], [cw])
+
+
 def test_identity_pose_returns_shaped_template():
     from audio_motion_avatar_amd import ops
 
