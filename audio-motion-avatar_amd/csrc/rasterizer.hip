@@ -38,6 +38,9 @@
 namespace amav {
 namespace raster {
 
+#ifndef AMAV_BIN_ABLATE
+#define AMAV_BIN_ABLATE 0  /* diagnostic builds of the binning kernel only (tools/stamp_bin.sh) */
+#endif
 #ifndef AMAV_ABLATE
 #define AMAV_ABLATE 0  /* diagnostic builds of the blend kernel only (tools/): never set in the product */
 #endif
@@ -89,8 +92,9 @@ static Buffers carve(void *ws, int F, int N, int gx, int gy, long long cap, size
     Carver c(ws);
     Buffers b;
     b.status = c.take<Status>(1);
-    b.geom = c.take<float4>((size_t)F * N * 3);
-    b.rectd = c.take<uint4>((size_t)F * N);
+    // + 1024 spare records behind the last frame: where the binning block's lanes past the end of a frame store
+    b.geom = c.take<float4>(((size_t)F * N + 1024) * 3);
+    b.rectd = c.take<uint4>((size_t)F * N + 1024);
     b.tile_off = c.take<int>((size_t)F * (T + 1));
     b.keys = c.take<unsigned long long>((size_t)cap);
     b.sorted = c.take<unsigned>((size_t)cap);
@@ -170,10 +174,30 @@ __device__ __forceinline__ GaussRec load_gaussian(const Params &p, int f, int i)
     return g;
 }
 
-__device__ __forceinline__ uint4 preprocess_one(const Params &p, int f, int i, const GaussRec &rec, const float *vm,
-                                                const float *pm, float tanx, float tany, int &upstream_tiles) {
+// A frame's camera, read ONCE per block into scalar registers.  Passed as pointers, the binning loop re-read the two
+// matrices from memory for every Gaussian (the compiler cannot prove that the loop's stores leave them alone): eight
+// vector loads per iteration that queued behind the previous iteration's stores -- a wave's vector-memory operations
+// complete in order -- and, waited for with vmcnt(0), drained the prefetch of the next record as well.
+struct FrameCamera {
+    float vm[16], pm[16];  // column-major view / projection (as the rasterizer's arguments hold them)
+    float tanx, tany;
+};
+__device__ __forceinline__ FrameCamera load_camera(const Params &p, int f) {
+    FrameCamera c;
+    auto uniform = [](float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); };
+#pragma unroll
+    for (int k = 0; k < 16; ++k) c.vm[k] = uniform(p.view[f * 16 + k]), c.pm[k] = uniform(p.proj[f * 16 + k]);
+    c.tanx = uniform(p.tanfov[2 * f]), c.tany = uniform(p.tanfov[2 * f + 1]);
+    return c;
+}
+
+// Returns the binning record {tile box, depth bits, radius} (radius 0 = culled) and, for a kept Gaussian, its blend record
+// in g[0..2] (the caller stores it to buf.geom).
+__device__ __forceinline__ uint4 preprocess_one(const Params &p, const GaussRec &rec, const FrameCamera &cam,
+                                                int &upstream_tiles, float4 (&g)[3]) {
 #pragma clang fp contract(off)
-    const size_t gi = (size_t)f * p.N + i;
+    const float *vm = cam.vm, *pm = cam.pm;
+    const float tanx = cam.tanx, tany = cam.tany;
     uint4 rd = make_uint4(0u, 0u, 0u, 0u);
     const float4 rec0 = rec.r0, rec1 = rec.r1, rec2 = rec.r2, rec3 = rec.r3;
     const float px3 = rec0.x, py3 = rec0.y, pz3 = rec0.z;
@@ -287,7 +311,6 @@ __device__ __forceinline__ uint4 preprocess_one(const Params &p, int f, int i, c
     if (cx1 <= cx0 || cy1 <= cy0) cx0 = cx1 = cy0 = cy1 = 0;
     rd = make_uint4((unsigned)cx0 | ((unsigned)cy0 << 16), (unsigned)cx1 | ((unsigned)cy1 << 16), __float_as_uint(vz),
                     (unsigned)(int)my_radius);
-    float4 *g = p.buf.geom + gi * 3;
     // The blend needs log2(alpha) = log2(op) + log2(e) * power, power = -1/2 (A dx^2 + C dy^2) - B dx dy with the conic
     // (A, B, C) = (cc, -cb, ca) / det.  The quadratic form is stored as its Cholesky factor: with k = log2(e) / 2,
     //     -log2(e) * power = (a dx + b dy)^2 + (c dy)^2,   a = sqrt(k A), b = k B / a, c = sqrt(k (C - B^2 / A)) = sqrt(k / cc)
@@ -337,10 +360,15 @@ __global__ __launch_bounds__(256) void preprocess_kernel(Params p) {
     int up = 0;
     if (i < p.N) {
         const GaussRec rec = load_gaussian<kPacked>(p, f, i);
-        const uint4 rd = preprocess_one(p, f, i, rec, p.view + f * 16, p.proj + f * 16, p.tanfov[2 * f], p.tanfov[2 * f + 1], up);
+        float4 g[3];
+        const uint4 rd = preprocess_one(p, rec, load_camera(p, f), up, g);
         const size_t gi = (size_t)f * p.N + i;
         p.buf.rectd[gi] = rd;
         if (p.out_radii) p.out_radii[gi] = (int)rd.w;
+        if (rd.w) {
+            float4 *dst = p.buf.geom + gi * 3;
+            dst[0] = g[0], dst[1] = g[1], dst[2] = g[2];
+        }
     }
     // upstream's instance count (3-sigma rectangles), summed per block
     __shared__ int part[4];
@@ -364,31 +392,69 @@ __global__ __launch_bounds__(1024) void bin_kernel(Params p) {
     int *cursor = bin_lds + p.T;
     int *scratch = bin_lds + 2 * p.T + 3 * kQueues * (kBuckets + 1);
     const int f = blockIdx.x;
+#ifdef AMAV_BIN_STAMPS  /* diagnostic build (tools/stamp_bin.sh): block-level phase stamps behind the blend kernel's */
+#define AMAV_BIN_STAMP(k)                                                                                        \
+    do {                                                                                                         \
+        __syncthreads();                                                                                         \
+        if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)p.F * p.T * 6 + (size_t)f * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define AMAV_BIN_STAMP(k)
+#endif
+    AMAV_BIN_STAMP(0);
     for (int t = threadIdx.x; t < p.T; t += blockDim.x) counts[t] = 0;
     __syncthreads();
 
     // phase 1: count instances per tile (LDS atomics)
     if (kFused) {
-        const float *vm = p.view + f * 16;
-        const float *pm = p.proj + f * 16;
-        const float tanx = p.tanfov[2 * f], tany = p.tanfov[2 * f + 1];
+        const FrameCamera cam = load_camera(p, f);
         int upstream = 0;
-        // the next Gaussian's record is in flight while this one goes through the (long, dependent) projection maths
-        GaussRec cur = load_gaussian<kPacked>(p, f, min((int)threadIdx.x, p.N - 1));
-        for (int i = threadIdx.x; i < p.N; i += blockDim.x) {
-            const GaussRec nxt = load_gaussian<kPacked>(p, f, min(i + (int)blockDim.x, p.N - 1));
+        // Two Gaussians per thread and round, the NEXT round's two records requested before this round's results are
+        // stored.  A wave's vector-memory operations complete in order, so a wait for a load is also a wait for every
+        // store issued before it, and a store takes ~9 us to be acknowledged on a chip that is writing: with the plain
+        // order (store the result, fetch the next record, wait for it) every Gaussian paid for its predecessor's
+        // stores (tools/stamp_bin.sh at 250 x 10 000: this phase 88 us; 50.6 us without loads and stores, 52.9 with the
+        // stores only, 59.0 with the loads only).  Here the wait at the end of a round is for loads that were issued
+        // BEFORE the round's stores, and the stores it has to cover are a whole round old: 78 us.  For that to work the
+        // count of stores between a load and its wait must be the same on every path, so that `s_waitcnt vmcnt(8)` can
+        // step over them: every lane stores every time -- culled Gaussians a zero record (nobody reads it), lanes past
+        // the end of the frame into a spare slot behind the last frame.
+        auto pin = [](GaussRec &r) {  // the values count as produced here: the compiler's wait for the loads lands here
+            asm volatile(""
+                         : "+v"(r.r0.x), "+v"(r.r0.y), "+v"(r.r0.z), "+v"(r.r0.w), "+v"(r.r1.x), "+v"(r.r1.y), "+v"(r.r1.z),
+                           "+v"(r.r1.w), "+v"(r.r2.x), "+v"(r.r2.y), "+v"(r.r2.z), "+v"(r.r3.x), "+v"(r.r3.y), "+v"(r.r3.z));
+        };
+        const int B = blockDim.x;
+        auto project = [&](const GaussRec &rec, int i) {
             int up = 0;
-            const uint4 rd = preprocess_one(p, f, i, cur, vm, pm, tanx, tany, up);
-            cur = nxt;
+            float4 g[3] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+            uint4 rd = preprocess_one(p, rec, cam, up, g);
+            const bool real = i < p.N;
+            if (!real) rd = make_uint4(0u, 0u, 0u, 0u), up = 0;
             upstream += up;
-            const size_t gi = (size_t)f * p.N + i;
-            p.buf.rectd[gi] = rd;
-            if (p.out_radii) p.out_radii[gi] = (int)rd.w;
+#if AMAV_BIN_ABLATE != 1
             if (rd.w) {
                 const int rx0 = rd.x & 0xffff, ry0 = rd.x >> 16, rx1 = rd.y & 0xffff, ry1 = rd.y >> 16;
                 for (int ty = ry0; ty < ry1; ++ty)
                     for (int tx = rx0; tx < rx1; ++tx) atomicAdd(&counts[ty * p.gx + tx], 1);
             }
+#endif
+            const size_t gi = real ? (size_t)f * p.N + i : (size_t)p.F * p.N + threadIdx.x;  // spare slots: carve()
+            p.buf.rectd[gi] = rd;
+            float4 *dst = p.buf.geom + gi * 3;
+            dst[0] = g[0], dst[1] = g[1], dst[2] = g[2];
+        };
+        GaussRec a0 = load_gaussian<kPacked>(p, f, min((int)threadIdx.x, p.N - 1));
+        GaussRec a1 = load_gaussian<kPacked>(p, f, min((int)threadIdx.x + B, p.N - 1));
+        for (int base = 0; base < p.N; base += 2 * B) {  // block-uniform trip count
+            const int i = base + threadIdx.x;
+            GaussRec n0 = load_gaussian<kPacked>(p, f, min(i + 2 * B, p.N - 1));
+            GaussRec n1 = load_gaussian<kPacked>(p, f, min(i + 3 * B, p.N - 1));
+            project(a0, i);
+            project(a1, i + B);
+            pin(n0);
+            pin(n1);
+            a0 = n0, a1 = n1;
         }
         int upstream_total;
         block_exclusive_scan(upstream, scratch, &upstream_total);
@@ -408,6 +474,7 @@ __global__ __launch_bounds__(1024) void bin_kernel(Params p) {
         }
     }
     __syncthreads();
+    AMAV_BIN_STAMP(1);
 
     // phase 2: exclusive scan of the tile counters -> list offsets inside this frame's instance region
     const int per = (p.T + (int)blockDim.x - 1) / (int)blockDim.x;
@@ -432,6 +499,7 @@ __global__ __launch_bounds__(1024) void bin_kernel(Params p) {
         }
     }
     const bool fits = (long long)total <= p.cap_per_frame;
+    AMAV_BIN_STAMP(2);
     // slots of this frame's non-empty tiles in the wire buffer's payload: in tile order inside the frame, the frame's
     // range reserved with one atomic on the wire header's count (frames land in completion order; readers go through
     // the offsets table, so the order is immaterial)
@@ -497,20 +565,40 @@ __global__ __launch_bounds__(1024) void bin_kernel(Params p) {
     }
     __syncthreads();
     if (!fits) return;
+    AMAV_BIN_STAMP(3);
 
     // phase 3: scatter (depth, index) keys into the tile lists (order inside a list is fixed later by the sort)
     unsigned long long *keys = p.buf.keys + (size_t)f * p.cap_per_frame;
+    // The binning records of kScatterChunk Gaussians per thread are read up front and waited for ONCE, before the first
+    // key store: a load issued after the key stores of the previous Gaussian would wait for their acknowledgement
+    // (in-order vector memory, see phase 1) once per Gaussian; this way once per chunk, i.e. not at all up to 12 288
+    // Gaussians per frame.
     const uint4 *rect = p.buf.rectd + (size_t)f * p.N;
-    uint4 rd_next = rect[min((int)threadIdx.x, p.N - 1)];
-    for (int i = threadIdx.x; i < p.N; i += blockDim.x) {
-        const uint4 rd = rd_next;
-        rd_next = rect[min(i + (int)blockDim.x, p.N - 1)];
-        if (rd.w == 0u) continue;
-        const int rx0 = rd.x & 0xffff, ry0 = rd.x >> 16, rx1 = rd.y & 0xffff, ry1 = rd.y >> 16;
-        const unsigned long long key = ((unsigned long long)rd.z << 32) | (unsigned)i;
-        for (int ty = ry0; ty < ry1; ++ty)
-            for (int tx = rx0; tx < rx1; ++tx) keys[atomicAdd(&cursor[ty * p.gx + tx], 1)] = key;
+    constexpr int kScatterChunk = 12;
+    for (int base = threadIdx.x; base < p.N; base += kScatterChunk * (int)blockDim.x) {
+        uint4 rds[kScatterChunk];
+#pragma unroll
+        for (int k = 0; k < kScatterChunk; ++k) rds[k] = rect[min(base + k * (int)blockDim.x, p.N - 1)];
+#pragma unroll
+        for (int k = 0; k < kScatterChunk; k += 4)
+            asm volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(rds[k].x), "+v"(rds[k].y), "+v"(rds[k].z), "+v"(rds[k].w), "+v"(rds[k + 1].x), "+v"(rds[k + 1].y),
+                           "+v"(rds[k + 1].z), "+v"(rds[k + 1].w), "+v"(rds[k + 2].x), "+v"(rds[k + 2].y), "+v"(rds[k + 2].z),
+                           "+v"(rds[k + 2].w), "+v"(rds[k + 3].x), "+v"(rds[k + 3].y), "+v"(rds[k + 3].z), "+v"(rds[k + 3].w));
+#pragma unroll
+        for (int k = 0; k < kScatterChunk; ++k) {
+            const int i = base + k * (int)blockDim.x;
+            if (i >= p.N) break;
+            const uint4 rd = rds[k];
+            if (kFused && p.out_radii) p.out_radii[(size_t)f * p.N + i] = (int)rd.w;
+            if (rd.w == 0u) continue;
+            const int rx0 = rd.x & 0xffff, ry0 = rd.x >> 16, rx1 = rd.y & 0xffff, ry1 = rd.y >> 16;
+            const unsigned long long key = ((unsigned long long)rd.z << 32) | (unsigned)i;
+            for (int ty = ry0; ty < ry1; ++ty)
+                for (int tx = rx0; tx < rx1; ++tx) keys[atomicAdd(&cursor[ty * p.gx + tx], 1)] = key;
+        }
     }
+    AMAV_BIN_STAMP(4);
 }
 
 // ----------------------------------------------------------------------------------------------------------- sort
