@@ -159,6 +159,9 @@ SIGNATURES = {
                                               c_float_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "amav_points_gather": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_float_p, ctypes.c_void_p,
                                           c_float_p, ctypes.c_void_p]),
+    "amav_points_bbox": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_float_p, c_float_p, ctypes.c_void_p]),
+    "amav_triplane_project_region": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_float_p, ctypes.c_int64,
+                                                    c_float_p, c_float_p, c_float_p, ctypes.c_float, ctypes.c_void_p]),
     "amav_triplane_project": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_float_p, ctypes.c_int64,
                                              c_float_p, c_float_p, ctypes.c_void_p]),
     "amav_triplane_sample_decode": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_float_p, c_float_p,

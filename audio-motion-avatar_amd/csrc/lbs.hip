@@ -27,6 +27,10 @@
 
 #include "amav_common.h"
 
+#ifndef AMAV_LBS_ABLATE
+#define AMAV_LBS_ABLATE 0  /* diagnostic builds only (tools/ablate_lbs.sh) */
+#endif
+
 namespace amav {
 namespace lbs {
 
@@ -555,7 +559,11 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 3) void skin_f16_kernel(Tables t, 
     AMAV_LBS_STAGE(0, bn0, bn1, bn2)
     AMAV_LBS_GLOAD(bn0, bn1, bn2, min(1, nchunks - 1))
     __syncthreads();
+#if AMAV_LBS_ABLATE == 2  /* diagnostic: one chunk instead of the whole table (epilogue + start-up only) */
+    for (int ch = 0; ch < 1; ++ch) {
+#else
     for (int ch = 0; ch < nchunks; ++ch) {
+#endif
         const int buf = ch & 1;
         // always issued (the last iterations re-read the last chunk and discard it), as in skin_mfma_kernel
         AMAV_LBS_GLOAD(bf0, bf1, bf2, min(ch + 2, nchunks - 1))
@@ -579,6 +587,10 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 3) void skin_f16_kernel(Tables t, 
 #undef AMAV_LBS_STEP
     if (!active) return;
     if (v >= t.V) return;
+#if AMAV_LBS_ABLATE == 1  /* diagnostic (tools/ablate_lbs.sh, stand-alone timing only): no skinning epilogue */
+    if (X[0] + Y[3] + Z[7] == 12345.678f) out[0] = X[1];
+    return;
+#endif
 
     const float tx = t.v_template[v * 3], ty = t.v_template[v * 3 + 1], tz = t.v_template[v * 3 + 2];
     float fs_all[16];  // the scale of every accumulator row's frame

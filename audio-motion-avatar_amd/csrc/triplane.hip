@@ -29,13 +29,53 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // grid: (ceil(R*R/4 / 256), 3, F); each thread projects 4 consecutive texels of one plane.  The plane's [C][16] weight
 // block is staged in LDS once per workgroup and read back as broadcasts (as scalar loads its 16 KB per plane thrash
 // the 16 KB scalar cache when workgroups of different planes share a CU, putting an L2 round trip in every iteration).
+// The texels of plane `plane` that bilinear taps of points inside the box [lo, hi] (world space) can touch, with
+// sample_decode_kernel's own arithmetic (u = clamp(p / radius), pixel = ((u + 1) R - 1) / 2, taps floor and floor + 1,
+// out-of-range taps read the clamped address): every step is monotonic in p, so the taps of any point of the box --
+// in particular of any point the subdivision table averages from vertices inside it -- lie in the returned rectangle
+// [x0, x1] x [y0, y1] (inclusive, already clamped to the plane).
+struct TexelRect {
+    int x0, x1, y0, y1;
+};
+__device__ __forceinline__ int tap_floor(float p, float radius, int R) {
+    const float u = fminf(fmaxf(p / radius, -1.0f), 1.0f);
+    return (int)floorf(((u + 1.0f) * (float)R - 1.0f) * 0.5f);
+}
+__device__ __forceinline__ TexelRect region_of(const float *__restrict__ box, int plane, float radius, int R) {
+    // plane 0 <- (x, y), plane 1 <- (x, z), plane 2 <- (y, z); grid x indexes W, grid y indexes H
+    const int ax = plane == 2 ? 1 : 0, ay = plane == 0 ? 1 : 2;
+    TexelRect r;
+    r.x0 = min(max(tap_floor(box[ax], radius, R), 0), R - 1);
+    r.x1 = min(max(tap_floor(box[3 + ax], radius, R) + 1, 0), R - 1);
+    r.y0 = min(max(tap_floor(box[ay], radius, R), 0), R - 1);
+    r.y1 = min(max(tap_floor(box[3 + ay], radius, R) + 1, 0), R - 1);
+    return r;
+}
+
+// `boxes` (NULL = all texels): per frame the bounding box {min xyz, max xyz} of the points that will be sampled
+// (amav_points_bbox); texel quads outside the frame's region_of() are neither read nor written -- the body covers a
+// fifth to a third of each plane, and the slab is the largest stream of the whole path.
 template <int kUnroll, bool kNT>
 __global__ __launch_bounds__(256) void project_kernel(int C, int RR, const float *__restrict__ tokens,
                                                       long long frame_stride, const float *__restrict__ wplane,
-                                                      float *__restrict__ out) {
+                                                      float *__restrict__ out, const float *__restrict__ boxes,
+                                                      float radius, int R) {
     extern __shared__ __align__(16) float w_lds[];  // [C][16]
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;  // texel quad within the plane
-    const int plane = blockIdx.y, f = blockIdx.z;
+    // grid = (3 planes, F, blocks per plane): the block index inside the plane is the SLOWEST dimension, because with a
+    // region only the first few blocks of every plane have work and workgroups go to the 8 XCDs round-robin by their
+    // linear id -- as the fastest dimension the busy blocks of all planes would share a few XCDs
+    const int bx = blockIdx.z;
+    int q = bx * blockDim.x + threadIdx.x;  // texel quad within the plane
+    const int plane = blockIdx.x, f = blockIdx.y;
+    if (boxes) {
+        // the quads of the frame's rectangle, numbered row by row: thread group i of the plane's grid takes the i-th
+        // of them (full waves whatever the rectangle's width; the blocks past its last quad leave before the barrier)
+        const TexelRect rc = region_of(boxes + (size_t)f * 6, plane, radius, R);
+        const int c0 = rc.x0 >> 2, per_row = (rc.x1 >> 2) - c0 + 1, rows = rc.y1 - rc.y0 + 1;
+        if (bx * (int)blockDim.x >= per_row * rows) return;  // block-uniform
+        const int row = q / per_row;
+        q = row < rows ? (rc.y0 + row) * (R >> 2) + c0 + (q - row * per_row) : RR;  // RR: past the end, leaves below
+    }
     {
         const float4 *src4 = reinterpret_cast<const float4 *>(wplane + (size_t)plane * C * 16);
         float4 *dst4 = reinterpret_cast<float4 *>(w_lds);
@@ -331,14 +371,76 @@ __global__ __launch_bounds__(256) void sample_features_tiled_kernel(int N, int C
     }
 }
 
+// One 1024-thread block per frame: {min x, y, z, max x, y, z} of the frame's points, read as a flat run of 3N floats
+// (element e is component e % 3).  A frame that holds a NaN gets the infinite box (its sampling coordinates clamp to a
+// plane border the finite points may not reach).
+__global__ __launch_bounds__(1024) void bbox_kernel(int N, const float *__restrict__ points, float *__restrict__ boxes) {
+    __shared__ float part[16][7];
+    const int f = blockIdx.x;
+    const float *pp = points + (size_t)f * N * 3;
+    const int total = 3 * N;
+    float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+    float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    float bad = 0.f;
+    // three consecutive elements per thread and trip = one point when the frame starts on a point boundary (it does):
+    // element e0 + d is component d
+    for (int e0 = threadIdx.x * 3; e0 < total; e0 += blockDim.x * 3) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float v = pp[e0 + d];
+            lo[d] = fminf(lo[d], v), hi[d] = fmaxf(hi[d], v);
+            if (v != v) bad = 1.f;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            lo[d] = fminf(lo[d], __shfl_xor(lo[d], o, 64));
+            hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], o, 64));
+        }
+        bad = fmaxf(bad, __shfl_xor(bad, o, 64));
+    }
+    const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) part[wave][d] = lo[d], part[wave][3 + d] = hi[d];
+        part[wave][6] = bad;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int d = threadIdx.x;
+        float any_bad = 0.f, v = part[0][d];
+        for (int w = 0; w < nwaves; ++w) {
+            any_bad += part[w][6];
+            v = d < 3 ? fminf(v, part[w][d]) : fmaxf(v, part[w][d]);
+        }
+        if (any_bad > 0.f) v = d < 3 ? -__builtin_inff() : __builtin_inff();
+        boxes[(size_t)f * 6 + d] = v;
+    }
+}
+
 }  // namespace triplane
 }  // namespace amav
 
 using namespace amav;
 using namespace amav::triplane;
 
+extern "C" int amav_points_bbox(int F, int N, const float *points, float *out_boxes, void *stream) {
+    AMAV_REQUIRE(F > 0 && N > 0 && points && out_boxes, "amav_points_bbox: bad sizes F=%d N=%d or NULL pointer", F, N);
+    bbox_kernel<<<F, 1024, 0, static_cast<hipStream_t>(stream)>>>(N, points, out_boxes);
+    return check_launch("amav_points_bbox");
+}
+
 extern "C" int amav_triplane_project(int F, int C, int R, const float *tokens, int64_t frame_stride,
-                                     const float *wplane, float *out, void *stream_) {
+                                     const float *wplane, float *out, void *stream) {
+    return amav_triplane_project_region(F, C, R, tokens, frame_stride, wplane, out, nullptr, 1.0f, stream);
+}
+
+extern "C" int amav_triplane_project_region(int F, int C, int R, const float *tokens, int64_t frame_stride,
+                                            const float *wplane, float *out, const float *boxes, float radius,
+                                            void *stream_) {
+    AMAV_REQUIRE(boxes == nullptr || radius > 0.0f, "amav_triplane_project: radius must be positive");
     AMAV_REQUIRE(F > 0 && C > 0 && R > 0, "amav_triplane_project: bad sizes F=%d C=%d R=%d", F, C, R);
     AMAV_REQUIRE(tokens && wplane && out, "amav_triplane_project: NULL pointer");
     AMAV_REQUIRE(F <= 65535, "amav_triplane_project: F=%d exceeds grid.z", F);
@@ -348,19 +450,20 @@ extern "C" int amav_triplane_project(int F, int C, int R, const float *tokens, i
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int RR = R * R;
     const bool vec = (RR % 4 == 0) && (frame_stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(tokens) & 15) == 0);
+    if (R % 4 != 0) boxes = nullptr;  // the rectangle is walked in quads of one row; other resolutions project everything
     if (vec) {
-        const dim3 grid((RR / 4 + 255) / 256, 3, F);
         // 786 MB slab: 140 us (5.6 TB/s) with the double-buffered loads at 4 channels per buffer (8: 149 us, 2: 145 us); the
         // single unrolled loop it replaces drained its loads at every trip and stopped at 216 us (3.6 TB/s).
         // AMAV_PROJECT_UNROLL = 2 / 4 / 8 is a tuning aid.
         static const int unroll = getenv("AMAV_PROJECT_UNROLL") ? atoi(getenv("AMAV_PROJECT_UNROLL")) : 4;
         const size_t lds = (size_t)C * 16 * sizeof(float);
+        const dim3 grid(3, F, (RR / 4 + 255) / 256);
         if (unroll == 8)
-            project_kernel<8, true><<<grid, 256, lds, stream>>>(C, RR, tokens, frame_stride, wplane, out);
+            project_kernel<8, true><<<grid, 256, lds, stream>>>(C, RR, tokens, frame_stride, wplane, out, boxes, radius, R);
         else if (unroll == 2)
-            project_kernel<2, true><<<grid, 256, lds, stream>>>(C, RR, tokens, frame_stride, wplane, out);
+            project_kernel<2, true><<<grid, 256, lds, stream>>>(C, RR, tokens, frame_stride, wplane, out, boxes, radius, R);
         else
-            project_kernel<4, true><<<grid, 256, lds, stream>>>(C, RR, tokens, frame_stride, wplane, out);
+            project_kernel<4, true><<<grid, 256, lds, stream>>>(C, RR, tokens, frame_stride, wplane, out, boxes, radius, R);
     } else {
         const dim3 grid((RR + 255) / 256, 3, F);
         project_kernel_scalar<<<grid, 256, 0, stream>>>(C, RR, tokens, frame_stride, wplane, out);

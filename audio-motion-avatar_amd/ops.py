@@ -477,8 +477,21 @@ def pack_head_weights(weights: dict, channels: int, device):
     return w_plane, w_point
 
 
-def triplane_project(tokens, head_w_plane, resolution):
-    """tokens [F, C, 3*R*R] (reference token layout, renderer.py:85-91) -> projected planes [F,3,R,R,16]."""
+def points_bbox(points):
+    """points [F,N,3] -> [F,6] = per frame (min xyz, max xyz); a frame with a NaN gets the infinite box."""
+    points = _contig(points, "points")
+    if points.dim() != 3 or points.shape[-1] != 3:
+        raise AmavError(f"points_bbox: expected [F,N,3], got {tuple(points.shape)}")
+    F, N = int(points.shape[0]), int(points.shape[1])
+    out = torch.empty(F, 6, device=points.device)
+    check(_lib.lib().amav_points_bbox(F, N, points.data_ptr(), out.data_ptr(), _stream()), "amav_points_bbox")
+    return out
+
+
+def triplane_project(tokens, head_w_plane, resolution, region=None, out=None):
+    """tokens [F, C, 3*R*R] (reference token layout, renderer.py:85-91) -> projected planes [F,3,R,R,16].
+    `region` = (boxes [F,6] from points_bbox, radius): only the texels that sampling points inside the boxes can touch
+    are projected (include/amav.h, amav_triplane_project_region); the others are left unwritten (of `out`, when given)."""
     _need(tokens, "tokens")
     if tokens.dim() != 3 or tokens.stride(2) != 1 or tokens.stride(1) != tokens.shape[2]:
         tokens = tokens.contiguous()
@@ -489,9 +502,19 @@ def triplane_project(tokens, head_w_plane, resolution):
     head_w_plane = _contig(head_w_plane, "head_w_plane")
     if tuple(head_w_plane.shape) != (3, C, 16):
         raise AmavError(f"head_w_plane {tuple(head_w_plane.shape)} != {(3, C, 16)}")
-    out = torch.empty(F, 3, R, R, 16, device=tokens.device)
-    check(_lib.lib().amav_triplane_project(F, C, R, tokens.data_ptr(), tokens.stride(0), head_w_plane.data_ptr(),
-                                           out.data_ptr(), _stream()), "amav_triplane_project")
+    if out is None:
+        out = torch.empty(F, 3, R, R, 16, device=tokens.device)
+    elif tuple(out.shape) != (F, 3, R, R, 16) or not out.is_contiguous() or out.dtype != torch.float32 or not out.is_cuda:
+        raise AmavError(f"triplane_project: out must be a contiguous float32 device tensor {(F, 3, R, R, 16)}")
+    boxes, radius = None, 1.0
+    if region is not None:
+        boxes, radius = region
+        boxes = _contig(boxes, "region boxes")
+        if tuple(boxes.shape) != (F, 6) or not float(radius) > 0.0:
+            raise AmavError(f"triplane_project: region boxes {tuple(boxes.shape)} != {(F, 6)} or radius {radius} <= 0")
+    check(_lib.lib().amav_triplane_project_region(F, C, R, tokens.data_ptr(), tokens.stride(0), head_w_plane.data_ptr(),
+                                                  out.data_ptr(), boxes.data_ptr() if boxes is not None else None,
+                                                  float(radius), _stream()), "amav_triplane_project_region")
     return out
 
 

@@ -97,6 +97,7 @@ class Renderer(nn.Module):
         nn.init.constant_(self.gaussian_decoder.opacity_layer.bias, inverse_sigmoid(0.1))
         self._packed = None
         self._chunk_streams = []
+        self.project_sampled_region = os.environ.get("AMAV_PROJECT_REGION", "1") != "0"
         self.to(cfg.device)
 
     # ---- body model ------------------------------------------------------------------------------------------
@@ -189,30 +190,27 @@ class Renderer(nn.Module):
     def gaussians_from_tokens(self, triplane_tokens, smpl_params, out=None, side_work=None, window_plan=None):
         """renderer.py:127-181 as one fused stage: tokens [F,C,3R^2] + SMPL-X params -> packed Gaussians [F,N,16].
 
-        Everything is enqueued on the calling stream: slab projection, camera set-up (`side_work`, an optional
-        callable whose result is returned as a second value), LBS chain, then the sampling kernel with the densify +
-        subset gather folded in.  (Round 1 ran the projection on a helper stream; measured worth nothing -- 1.148 vs
+        Everything is enqueued on the calling stream: camera set-up (`side_work`, an optional callable whose result is
+        returned as a second value), LBS chain, slab projection (of the region the posed body can sample), then the
+        sampling kernel with the densify + subset gather folded in.  (Round 1 ran the projection on a helper stream; measured worth nothing -- 1.148 vs
         1.137 ms per 250-frame step -- and a fork/join graph only hid the hipMemsetAsync replay fault described in
         DESIGN.md section 1.)  `window_plan`: the windowed upsampler's plan for exactly these frames (mask [F,g,g] per
         plane); refined points that leave it raise _WindowTooSmall.
         """
         F = triplane_tokens.shape[0]
         w_plane, w_point = self._head_weights()
-        if os.environ.get("AMAV_SIDE_LBS") == "1" and not hasattr(self, "point_encoder"):
-            cur = torch.cuda.current_stream()
-            if getattr(self, "_lbs_stream", None) is None:
-                self._lbs_stream = torch.cuda.Stream(device=triplane_tokens.device)
-            self._lbs_stream.wait_stream(cur)
-            with torch.cuda.stream(self._lbs_stream):
-                side_result = side_work() if side_work is not None else None
-                vertices = self._posed_vertices(smpl_params)
-            proj = ops.triplane_project(triplane_tokens, w_plane, self._plane_resolution(triplane_tokens))
-            cur.wait_stream(self._lbs_stream)
-        else:
-            proj = ops.triplane_project(triplane_tokens, w_plane, self._plane_resolution(triplane_tokens))
-            side_result = side_work() if side_work is not None else None
-            vertices = self._posed_vertices(smpl_params)
+        R = self._plane_resolution(triplane_tokens)
+        side_result = side_work() if side_work is not None else None
+        vertices = self._posed_vertices(smpl_params)
         transl = smpl_params["transl"].reshape(F, 3).float()
+
+        # The slab is projected only where the frame's points can sample it: the box of the posed vertices (the
+        # subdivision table averages vertices, so its points stay inside) or of the refined points; the avatar covers a
+        # fifth to a third of each plane, and the slab is the largest stream of the path (ops.triplane_project).
+        def project(points_like):
+            region = (ops.points_bbox(points_like), self.cfg.radius) if self.project_sampled_region else None
+            return ops.triplane_project(triplane_tokens, w_plane, R, region=region)
+
         if hasattr(self, "point_encoder"):
             if self.cfg.densify_smplx_verts:
                 vertices = ops.points_gather(vertices, self._gather_idx)
@@ -220,12 +218,12 @@ class Renderer(nn.Module):
             if window_plan is not None and not self.triplane_upsampler.windows_contain(
                     window_plan, points, self.cfg.triplane_resolution, self.cfg.radius):
                 raise _WindowTooSmall()
-            packed = ops.triplane_sample_decode(proj, points, transl, self.cfg.radius, w_point, out=out)
+            packed = ops.triplane_sample_decode(project(points), points, transl, self.cfg.radius, w_point, out=out)
         elif self.cfg.densify_smplx_verts:
-            packed = ops.triplane_sample_decode_indexed(proj, vertices, self._gather_idx, transl, self.cfg.radius,
-                                                        w_point, out=out)
+            packed = ops.triplane_sample_decode_indexed(project(vertices), vertices, self._gather_idx, transl,
+                                                        self.cfg.radius, w_point, out=out)
         else:
-            packed = ops.triplane_sample_decode(proj, vertices, transl, self.cfg.radius, w_point, out=out)
+            packed = ops.triplane_sample_decode(project(vertices), vertices, transl, self.cfg.radius, w_point, out=out)
         return packed if side_work is None else (packed, side_result)
 
     def render_tokens(self, triplane_tokens, smpl_params, cam_params, chunks=1, workspaces=None, check_overflow=True,

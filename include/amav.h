@@ -257,6 +257,18 @@ int amav_points_gather(int num_frames, int num_verts, int num_points, const floa
 int amav_triplane_project(int num_frames, int channels, int resolution, const float *tokens_dev,
                           int64_t tokens_frame_stride, const float *head_w_plane_dev, float *out_proj_dev,
                           void *stream);
+/* The same, restricted to the texels the sampling can touch: boxes [F,6] = {min x, y, z, max x, y, z} of the points
+ * (amav_points_bbox of the point set handed to amav_triplane_sample_decode, or of the posed vertices the subdivision
+ * table of amav_triplane_sample_decode_indexed averages: a midpoint lies inside the box of its ends in floating point
+ * too), radius as in the sampling call.  Every tap address the sampling kernels form for a point inside the box --
+ * including the clamped addresses of zero-padded taps -- lies inside the projected rectangle (each step of
+ * p -> texel is monotonic), so the decoded Gaussians are bit-identical; texels outside are left unwritten.  The avatar
+ * covers a fifth to a third of each plane, and the token slab is the largest stream of the path.  boxes = NULL: all. */
+int amav_triplane_project_region(int num_frames, int channels, int resolution, const float *tokens_dev,
+                                 int64_t tokens_frame_stride, const float *head_w_plane_dev, float *out_proj_dev,
+                                 const float *boxes_dev, float radius, void *stream);
+/* boxes [F,6] = per frame {min x, y, z, max x, y, z} of points [F,N,3]; a frame holding a NaN gets the infinite box. */
+int amav_points_bbox(int num_frames, int num_points, const float *points_dev, float *out_boxes_dev, void *stream);
 /* points [F,N,3]; transl [F,3] or NULL; proj [F,3,R,R,16] from amav_triplane_project.
  * out_gaussians [F,N,16] packed records: xyz = p + offset + transl, opacity (raw logit) | rot (normalised) |
  * scale (raw), 0 | color = sigmoid(shs), 0.   (renderer.py:333-344) */

@@ -122,3 +122,54 @@ def test_indexed_decode_equals_gather_then_decode_bitwise():
     a = ops.triplane_sample_decode(proj, ops.points_gather(verts, idx), transl.cuda(), 1.4, w_point)
     b = ops.triplane_sample_decode_indexed(proj, verts, idx, transl.cuda(), 1.4, w_point)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("F,N,C,R,spread", [(3, 2000, 64, 64, 0.35), (2, 500, 32, 32, 0.9), (2, 300, 16, 8, 3.0), (1, 64, 8, 4, 0.2)])
+def test_projection_of_the_sampled_region_gives_the_same_gaussians(F, N, C, R, spread):
+    """amav_triplane_project_region projects only the texels that points inside the frame's box can sample.  The planes
+    are poisoned with NaN first: had the sampling kernels formed one tap address outside the projected rectangle --
+    zero-padded taps read the clamped address with weight 0 -- the records would not be finite; they are bit-identical
+    to the full projection's, for direct points, for the indexed (subdivision) form with the box of the VERTICES, with
+    points beyond the radius (spread 3.0: clamped coordinates), and the rectangle really is a part of the plane."""
+    from audio_motion_avatar_amd import ops
+
+    tokens, _, transl, params = make_case(F * 7 + N, F, N, C, R)
+    g = torch.Generator().manual_seed(N)
+    centre = torch.randn(F, 1, 3, generator=g) * 0.2
+    points = (centre + torch.randn(F, N, 3, generator=g) * torch.tensor([0.3, 0.6, 0.12]) * spread).cuda()
+    radius = 1.4
+    heads = {n: (params[f"gaussian_decoder.{n}.weight"], params[f"gaussian_decoder.{n}.bias"])
+             for n in ("xyz_layer", "rotation_layer", "scaling_layer", "opacity_layer", "shs_layer")}
+    w_plane, w_point = ops.pack_head_weights(heads, C, "cuda")
+    tok = tokens.cuda()
+    full = ops.triplane_project(tok, w_plane, R)
+    want = ops.triplane_sample_decode(full, points, transl.cuda(), radius, w_point)
+    boxes = ops.points_bbox(points)
+    assert torch.equal(boxes[:, :3], points.min(1).values) and torch.equal(boxes[:, 3:], points.max(1).values)
+    part = torch.full((F, 3, R, R, 16), float("nan"), device="cuda")
+    ops.triplane_project(tok, w_plane, R, region=(boxes, radius), out=part)
+    written = ~torch.isnan(part[..., 0])
+    assert torch.equal(part[written], full[written])
+    if spread < 1.0 and R >= 32:
+        assert 0.02 < written.float().mean() < 0.7
+    got = ops.triplane_sample_decode(part, points, transl.cuda(), radius, w_point)
+    assert torch.isfinite(got).all() and torch.equal(got, want)
+    # the subdivision form: points are averages of vertices, the box is the vertices'
+    V = max(16, N // 3)
+    verts = points[:, :V].contiguous()
+    idx = torch.randint(0, V, (N, 4), generator=g, dtype=torch.int32).cuda()
+    part.fill_(float("nan"))
+    ops.triplane_project(tok, w_plane, R, region=(ops.points_bbox(verts), radius), out=part)
+    a = ops.triplane_sample_decode_indexed(part, verts, idx, transl.cuda(), radius, w_point)
+    b = ops.triplane_sample_decode_indexed(full, verts, idx, transl.cuda(), radius, w_point)
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+    # a NaN among the points: the whole plane is projected
+    bad = points.clone()
+    bad[0, 5, 1] = float("nan")
+    nb = ops.points_bbox(bad)
+    assert torch.isinf(nb[0]).all() and torch.isfinite(nb[1:]).all()
+    part.fill_(float("nan"))
+    ops.triplane_project(tok, w_plane, R, region=(nb, radius), out=part)
+    assert not torch.isnan(part[0]).any()
+    with pytest.raises(ops.AmavError):
+        ops.triplane_project(tok, w_plane, R, region=(boxes[:, :5], radius))
