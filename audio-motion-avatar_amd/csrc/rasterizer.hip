@@ -81,8 +81,13 @@ struct Buffers {
     int *big_list;             // [F*T] (frame * T + tile) of lists longer than kSortCap
     int4 *queue;               // [kQueues][kBuckets][qcap] non-empty tiles: {frame * T + tile, list offset in the frame's region, list length, 0}
     int *empty_list;           // [F*T] (frame * T + tile) of empty tiles
+    int *slice_counts;         // [F][slices][T] few-frame shards: per-tile counts of every slice of a frame, then their prefix over the slices
     Status *status;
 };
+
+// Few frames (F < kFusedMinFrames): a frame's Gaussians are counted and scattered by several blocks ("slices"), so that
+// 6 or 32 frames still spread over the chip; ~256 blocks in all, at most 16 per frame.
+static inline int bin_slices(int F) { return F >= kFusedMinFrames ? 0 : std::min(16, std::max(1, (256 + F - 1) / F)); }
 
 // a queue holds, of every frame, one band of tile rows (bin_kernel): at most ceil(gy / kQueues) rows of gx tiles
 static inline size_t queue_capacity(int F, int gx, int gy) { return (size_t)F * ((gy + kQueues - 1) / kQueues) * gx; }
@@ -101,6 +106,7 @@ static Buffers carve(void *ws, int F, int N, int gx, int gy, long long cap, size
     b.big_list = c.take<int>((size_t)F * T);
     b.queue = c.take<int4>((size_t)kQueues * kBuckets * queue_capacity(F, gx, gy));
     b.empty_list = c.take<int>((size_t)F * T);
+    b.slice_counts = c.take<int>((size_t)F * bin_slices(F) * T);
     if (bytes) *bytes = c.total();
     return b;
 }
@@ -125,6 +131,7 @@ struct Params {
     unsigned char *wire_payload;
     int wire_cap;
     unsigned wire_bg;
+    int slices;  // few-frame shards: blocks per frame of slice_count_kernel / slice_scatter_kernel (bin_slices)
     Buffers buf;
 };
 
@@ -461,16 +468,17 @@ __global__ __launch_bounds__(1024) void bin_kernel(Params p) {
         if (threadIdx.x == 0)
             atomicAdd(reinterpret_cast<unsigned long long *>(&p.buf.status->total), (unsigned long long)upstream_total);
     } else {
-        const uint4 *rect = p.buf.rectd + (size_t)f * p.N;
-        uint4 rd_next = rect[min((int)threadIdx.x, p.N - 1)];
-        for (int i = threadIdx.x; i < p.N; i += blockDim.x) {
-            const uint4 rd = rd_next;
-            rd_next = rect[min(i + (int)blockDim.x, p.N - 1)];
-            if (rd.w) {
-                const int rx0 = rd.x & 0xffff, ry0 = rd.x >> 16, rx1 = rd.y & 0xffff, ry1 = rd.y >> 16;
-                for (int ty = ry0; ty < ry1; ++ty)
-                    for (int tx = rx0; tx < rx1; ++tx) atomicAdd(&counts[ty * p.gx + tx], 1);
+        // the frame was counted in slices (slice_count_kernel): sum them, and leave in every slice's entry the number of
+        // instances the slices before it put on the tile (slice_scatter_kernel starts its cursors there)
+        int *sc = p.buf.slice_counts + (size_t)f * p.slices * p.T;
+        for (int t = threadIdx.x; t < p.T; t += blockDim.x) {
+            int run = 0;
+            for (int b = 0; b < p.slices; ++b) {
+                const int c = sc[(size_t)b * p.T + t];
+                sc[(size_t)b * p.T + t] = run;
+                run += c;
             }
+            counts[t] = run;
         }
     }
     __syncthreads();
@@ -566,6 +574,7 @@ __global__ __launch_bounds__(1024) void bin_kernel(Params p) {
     __syncthreads();
     if (!fits) return;
     AMAV_BIN_STAMP(3);
+    if (!kFused) return;  // few-frame shards: slice_scatter_kernel writes the keys
 
     // phase 3: scatter (depth, index) keys into the tile lists (order inside a list is fixed later by the sort)
     unsigned long long *keys = p.buf.keys + (size_t)f * p.cap_per_frame;
@@ -599,6 +608,72 @@ __global__ __launch_bounds__(1024) void bin_kernel(Params p) {
         }
     }
     AMAV_BIN_STAMP(4);
+}
+
+// Few-frame shards, pass 1 of 3: grid (slices, F); the block counts the instances of its slice of the frame's Gaussians
+// per tile (LDS atomics over the binning records of preprocess_kernel) and leaves the counts in slice_counts.
+__global__ __launch_bounds__(1024) void slice_count_kernel(Params p) {
+    extern __shared__ int slice_lds[];
+    int *counts = slice_lds;
+    const int b = blockIdx.x, f = blockIdx.y;
+    for (int t = threadIdx.x; t < p.T; t += blockDim.x) counts[t] = 0;
+    __syncthreads();
+    const int per = (p.N + p.slices - 1) / p.slices;
+    const int i1 = min(p.N, (b + 1) * per);
+    const uint4 *rect = p.buf.rectd + (size_t)f * p.N;
+    for (int i = b * per + threadIdx.x; i < i1; i += blockDim.x) {
+        const uint4 rd = rect[i];
+        if (rd.w) {
+            const int rx0 = rd.x & 0xffff, ry0 = rd.x >> 16, rx1 = rd.y & 0xffff, ry1 = rd.y >> 16;
+            for (int ty = ry0; ty < ry1; ++ty)
+                for (int tx = rx0; tx < rx1; ++tx) atomicAdd(&counts[ty * p.gx + tx], 1);
+        }
+    }
+    __syncthreads();
+    int *out = p.buf.slice_counts + ((size_t)f * p.slices + b) * p.T;
+    for (int t = threadIdx.x; t < p.T; t += blockDim.x) out[t] = counts[t];
+}
+
+// Pass 3 of 3 (pass 2 is bin_kernel<false, .>: sums the slices, scans the tiles, builds the queues): the block scatters
+// the keys of its slice, its cursors starting behind the slices before it.  A frame that overflowed its region
+// (tile_off[T] = its instance count) is skipped, as the one-block form does.
+__global__ __launch_bounds__(1024) void slice_scatter_kernel(Params p) {
+    extern __shared__ int slice_lds[];
+    int *cursor = slice_lds;
+    const int b = blockIdx.x, f = blockIdx.y;
+    const int *off = p.buf.tile_off + (size_t)f * (p.T + 1);
+    if ((long long)off[p.T] > p.cap_per_frame) return;
+    const int *before = p.buf.slice_counts + ((size_t)f * p.slices + b) * p.T;
+    for (int t = threadIdx.x; t < p.T; t += blockDim.x) cursor[t] = off[t] + before[t];
+    __syncthreads();
+    const int per = (p.N + p.slices - 1) / p.slices;
+    const int i1 = min(p.N, (b + 1) * per);
+    unsigned long long *keys = p.buf.keys + (size_t)f * p.cap_per_frame;
+    const uint4 *rect = p.buf.rectd + (size_t)f * p.N;
+    // binning records first, key stores after (one wait per chunk: see bin_kernel's scatter)
+    constexpr int kChunk = 8;
+    for (int base = b * per + threadIdx.x; base < i1; base += kChunk * (int)blockDim.x) {
+        uint4 rds[kChunk];
+#pragma unroll
+        for (int k = 0; k < kChunk; ++k) rds[k] = rect[min(base + k * (int)blockDim.x, i1 - 1)];
+#pragma unroll
+        for (int k = 0; k < kChunk; k += 4)
+            asm volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(rds[k].x), "+v"(rds[k].y), "+v"(rds[k].z), "+v"(rds[k].w), "+v"(rds[k + 1].x), "+v"(rds[k + 1].y),
+                           "+v"(rds[k + 1].z), "+v"(rds[k + 1].w), "+v"(rds[k + 2].x), "+v"(rds[k + 2].y), "+v"(rds[k + 2].z),
+                           "+v"(rds[k + 2].w), "+v"(rds[k + 3].x), "+v"(rds[k + 3].y), "+v"(rds[k + 3].z), "+v"(rds[k + 3].w));
+#pragma unroll
+        for (int k = 0; k < kChunk; ++k) {
+            const int i = base + k * (int)blockDim.x;
+            if (i >= i1) break;
+            const uint4 rd = rds[k];
+            if (rd.w == 0u) continue;
+            const int rx0 = rd.x & 0xffff, ry0 = rd.x >> 16, rx1 = rd.y & 0xffff, ry1 = rd.y >> 16;
+            const unsigned long long key = ((unsigned long long)rd.z << 32) | (unsigned)i;
+            for (int ty = ry0; ty < ry1; ++ty)
+                for (int tx = rx0; tx < rx1; ++tx) keys[atomicAdd(&cursor[ty * p.gx + tx], 1)] = key;
+        }
+    }
 }
 
 // ----------------------------------------------------------------------------------------------------------- sort
@@ -1764,6 +1839,7 @@ extern "C" int amav_rasterize_forward(const amav_raster_args *a, void *stream_) 
     p.stamps = static_cast<unsigned long long *>(a->debug_stamps);
     p.wire_header = nullptr, p.wire_frame_counts = nullptr, p.wire_offsets = nullptr, p.wire_payload = nullptr;
     p.wire_cap = 0, p.wire_bg = 0;
+    p.slices = bin_slices(F);
     if (a->wire) {
         AMAV_REQUIRE(a->clamp_output, "amav_rasterize_forward: the wire output carries the clamped colours (set clamp_output)");
         AMAV_REQUIRE((reinterpret_cast<uintptr_t>(a->wire) & 15) == 0 && a->wire_capacity_tiles >= 0 &&
@@ -1783,11 +1859,13 @@ extern "C" int amav_rasterize_forward(const amav_raster_args *a, void *stream_) 
     }
 
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    static const hipError_t attr[3] = {
+    static const hipError_t attr[5] = {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&slice_count_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&slice_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
         hipFuncSetAttribute(reinterpret_cast<const void *>(&bin_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
         hipFuncSetAttribute(reinterpret_cast<const void *>(&bin_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
         hipFuncSetAttribute(reinterpret_cast<const void *>(&bin_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)};
-    if (attr[0] != hipSuccess || attr[1] != hipSuccess || attr[2] != hipSuccess)
+    if (attr[0] != hipSuccess || attr[1] != hipSuccess || attr[2] != hipSuccess || attr[3] != hipSuccess || attr[4] != hipSuccess)
         return fail(AMAV_ERR_LAUNCH, "amav_rasterize_forward: cannot raise the dynamic LDS limit");
     // packed-record fast path: the attributes are the xyz|opacity|rot|scale|color views of one [.., 16] buffer
     const float *b0 = a->means3d.ptr;
@@ -1814,7 +1892,10 @@ extern "C" int amav_rasterize_forward(const amav_raster_args *a, void *stream_) 
             preprocess_kernel<true><<<pre_grid, 256, 0, stream>>>(p);
         else
             preprocess_kernel<false><<<pre_grid, 256, 0, stream>>>(p);
+        const dim3 slice_grid((unsigned)p.slices, (unsigned)F);
+        slice_count_kernel<<<slice_grid, 1024, (size_t)T * sizeof(int), stream>>>(p);
         bin_kernel<false, false><<<F, 1024, bin_lds, stream>>>(p);
+        slice_scatter_kernel<<<slice_grid, 1024, (size_t)T * sizeof(int), stream>>>(p);
     } else if (packed)
         bin_kernel<true, true><<<F, 1024, bin_lds, stream>>>(p);
     else
