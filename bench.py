@@ -980,6 +980,8 @@ def main():
         gather.wait()
     torch.cuda.synchronize()
     if dist is not None:
+        dist.barrier()  # (twice: whatever the collective library sets up lazily for a barrier is paid here, not at
+        torch.cuda.synchronize()  # the barrier that closes the timed region)
         dist.barrier()
     step_marks = [ops.Event() for _ in range(args.steps + 1)]  # device-side duration of every step
     t0 = time.perf_counter()
@@ -987,12 +989,17 @@ def main():
     for i in range(args.steps):
         out = timed_step(i)
         step_marks[i + 1].record()
+    _dbg = os.environ.get("AMAV_BENCH_DEBUG") == "1"
+    _t1 = time.perf_counter()
     if gather is not None:
         gather.wait()
     torch.cuda.synchronize()
+    _t2 = time.perf_counter()
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    if _dbg:
+        print(f"[debug] enqueue {(_t1 - t0) * 1e3:.2f} ms, drain {(_t2 - _t1) * 1e3:.2f} ms, barrier {(time.perf_counter() - _t2) * 1e3:.2f} ms", file=sys.stderr)
     ops.PROFILE_EVENTS = None
     step_ms = sorted(step_marks[i].elapsed_ms(step_marks[i + 1]) for i in range(args.steps))
     if dist is not None:
