@@ -147,6 +147,19 @@ __device__ __forceinline__ int opaque(int x) {
     asm volatile("" : "+v"(x));
     return x;
 }
+// The lane id, recomputed where it is asked for (two instructions): kept in a register across the blend kernel's tile loop
+// it was spilled, and its reload -- a scratch load, i.e. a vector-memory operation -- waited for the wave's stores.
+__device__ __forceinline__ int lane_now() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+// A zero the optimiser cannot hoist (and then spill): materialised where it is used.
+__device__ __forceinline__ unsigned zero_now() {
+    unsigned z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    return z;
+}
 
 __device__ __forceinline__ void wave_sync() {
     // LDS operations of one wave execute in order; this only stops the compiler from moving them.
@@ -676,6 +689,47 @@ __global__ __launch_bounds__(1024) void slice_scatter_kernel(Params p) {
     }
 }
 
+// Wave-wide min / max / inclusive sum WITHOUT ds_bpermute: __shfl_xor / __shfl_up keep one address register per
+// distance alive (the compiler hoists (lane ^ o) << 2 out of the tile loop: thirteen registers), and what did not fit
+// was spilled -- reloaded per tile as scratch loads, i.e. vector-memory operations whose s_waitcnt vmcnt(0) also drains
+// every background store issued before them.  DPP permutes inside rows of 16 lanes need no address; the four rows are
+// combined on the scalar unit (the results are wave-uniform anyway).
+template <int kCtrl>
+__device__ __forceinline__ unsigned dpp_permute(unsigned v) {  // every lane has a source for these controls
+    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, kCtrl, 0xf, 0xf, false);
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {  // all 64 lanes active
+    v = min(v, dpp_permute<0xB1>(v));   // quad_perm [1,0,3,2]
+    v = min(v, dpp_permute<0x4E>(v));   // quad_perm [2,3,0,1]
+    v = min(v, dpp_permute<0x141>(v));  // row_half_mirror
+    v = min(v, dpp_permute<0x140>(v));  // row_mirror: every lane of a row holds the row's minimum
+    const unsigned a = __builtin_amdgcn_readlane((int)v, 0), b = __builtin_amdgcn_readlane((int)v, 16);
+    const unsigned c = __builtin_amdgcn_readlane((int)v, 32), d = __builtin_amdgcn_readlane((int)v, 48);
+    return min(min(a, b), min(c, d));
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+    v = max(v, dpp_permute<0xB1>(v));
+    v = max(v, dpp_permute<0x4E>(v));
+    v = max(v, dpp_permute<0x141>(v));
+    v = max(v, dpp_permute<0x140>(v));
+    const unsigned a = __builtin_amdgcn_readlane((int)v, 0), b = __builtin_amdgcn_readlane((int)v, 16);
+    const unsigned c = __builtin_amdgcn_readlane((int)v, 32), d = __builtin_amdgcn_readlane((int)v, 48);
+    return max(max(a, b), max(c, d));
+}
+template <int kShift>
+__device__ __forceinline__ unsigned dpp_row_shr(unsigned v) {  // lane i of a row <- lane i - kShift, 0 at the row's start
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + kShift, 0xf, 0xf, false);
+}
+__device__ __forceinline__ unsigned wave_inclusive_sum_u32(unsigned v, int lane) {  // all 64 lanes active
+    v += dpp_row_shr<1>(v);
+    v += dpp_row_shr<2>(v);
+    v += dpp_row_shr<4>(v);
+    v += dpp_row_shr<8>(v);  // inclusive sums inside every row of 16
+    const unsigned r0 = __builtin_amdgcn_readlane((int)v, 15), r1 = __builtin_amdgcn_readlane((int)v, 31);
+    const unsigned r2 = __builtin_amdgcn_readlane((int)v, 47);
+    return v + (lane >= 16 ? r0 : 0u) + (lane >= 32 ? r1 : 0u) + (lane >= 48 ? r2 : 0u);
+}
+
 // ----------------------------------------------------------------------------------------------------------- sort
 // Normalised bitonic network: every comparator orders (lo, hi) ascending, so a tail of "+inf" needs no storage:
 // comparators whose hi index is past n are skipped.
@@ -860,6 +914,7 @@ struct WaveLds {
     float4 geo[65];   // +0     {k0, k1, qa, qb}
     float4 col[65];   // +1040  {r, g, b, 1/depth}
     float4 geo2[65];  // +2080  {qc, log2(opacity), -, -}: 16-byte slots like the other planes (one slot address serves all three)
+    int bucket_end[32];  // the queue's bucket table: entry b = queue positions before the end of bucket b (render_kernel)
 };
 static_assert(offsetof(WaveLds, col) - offsetof(WaveLds, geo) == 1040 && offsetof(WaveLds, geo2) - offsetof(WaveLds, geo) == 2080,
               "blend_quadrant's ds_read offsets");
@@ -921,11 +976,7 @@ __device__ __attribute__((noinline)) bool bucket_sort(const unsigned long long *
         const unsigned d = (unsigned)(k[m] >> 32);
         if (in) dmin = min(dmin, d), dmax = max(dmax, d);
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        dmin = min(dmin, (unsigned)__shfl_xor((int)dmin, o, 64));
-        dmax = max(dmax, (unsigned)__shfl_xor((int)dmax, o, 64));
-    }
+    dmin = wave_min_u32(dmin), dmax = wave_max_u32(dmax);
     const float scale = dmax > dmin ? (float)(kBuckets512 - 1) / (float)(dmax - dmin) : 0.0f;
     int b[KPL];
 #pragma unroll
@@ -955,14 +1006,8 @@ __device__ __attribute__((noinline)) bool bucket_sort(const unsigned long long *
         c[i] = tot;
         tot += ci;
     }
-    unsigned incl = tot;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const unsigned up = (unsigned)__shfl_up((int)incl, o, 64);
-        if (lane >= o) incl += up;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) big = max(big, (unsigned)__shfl_xor((int)big, o, 64));
+    const unsigned incl = wave_inclusive_sum_u32(tot, lane);
+    big = wave_max_u32(big);
     if (big > (unsigned)kBucketMax) {  // wave-uniform
         wave_sync();
 #pragma unroll
@@ -1282,16 +1327,15 @@ __device__ __forceinline__ void sort_prefetched(const unsigned long long (&k)[4]
         const unsigned d = (unsigned)(k[m] >> 32);
         if (lane + 64 * m < n) dmin = min(dmin, d), dmax = max(dmax, d);
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        dmin = min(dmin, (unsigned)__shfl_xor((int)dmin, o, 64));
-        dmax = max(dmax, (unsigned)__shfl_xor((int)dmax, o, 64));
-    }
+    dmin = wave_min_u32(dmin), dmax = wave_max_u32(dmax);
     const float scale = dmax > dmin ? (float)(kPrepBuckets - 1) / (float)(dmax - dmin) : 0.0f;
     int b[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) b[m] = min(kPrepBuckets - 1, (int)((float)((unsigned)(k[m] >> 32) - dmin) * scale));
-    reinterpret_cast<uint2 *>(cnt)[lane] = make_uint2(0u, 0u);  // 128 words of two 16-bit counts
+    {
+        const unsigned z = zero_now();
+        reinterpret_cast<uint2 *>(cnt)[lane] = make_uint2(z, z);  // 128 words of two 16-bit counts
+    }
     wave_sync();
     unsigned pos[4];
 #pragma unroll
@@ -1313,14 +1357,8 @@ __device__ __forceinline__ void sort_prefetched(const unsigned long long (&k)[4]
         c[i] = tot;
         tot += ci;
     }
-    unsigned incl = tot;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const unsigned up = (unsigned)__shfl_up((int)incl, o, 64);
-        if (lane >= o) incl += up;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) big = max(big, (unsigned)__shfl_xor((int)big, o, 64));
+    const unsigned incl = wave_inclusive_sum_u32(tot, lane);
+    big = wave_max_u32(big);
     if (big > (unsigned)kBucketMax) {  // wave-uniform: clustered depths, comparison sort
         wave_sync();
 #pragma unroll
@@ -1409,14 +1447,15 @@ __global__ __launch_bounds__(64, kRenderWavesPerSimd) void render_kernel(Params 
     // (Looked up in memory per tile, the walk was a chain of up to 17 dependent loads of the status block -- which the
     // kernel also updates atomically, so nothing could be kept in registers -- each queued behind the wave's stores.)
     int bucket_end = (lane < kBuckets && !st->overflow) ? st->qcount[q][lane] : 0;
-    const int bucket_len = bucket_end;
 #pragma unroll
     for (int d = 1; d < 32; d <<= 1) {  // kBuckets <= 32 lanes carry the table
         const int o = __shfl_up(bucket_end, d, 64);
         if (lane >= d) bucket_end += o;
     }
-    const int bucket_start = bucket_end - bucket_len;
     const int total = __builtin_amdgcn_readlane(bucket_end, kBuckets - 1);
+    // the table lives in LDS from here on (in a register it was spilled: see lane_now())
+    if (lane < 32) L.bucket_end[lane] = bucket_end;
+    wave_sync();
     int i_cur = blockIdx.x / kQueues;  // first round: static; afterwards the queue's shared cursor
     if (i_cur < total) {
         // expected tiles per wave, to spread this wave's background tiles over its blended ones
@@ -1425,9 +1464,10 @@ __global__ __launch_bounds__(64, kRenderWavesPerSimd) void render_kernel(Params 
         int *next = const_cast<int *>(&st->next[q][0]);
         const int4 *queue_q = p.buf.queue + (size_t)q * kBuckets * p.qcap;
         auto entry_of = [&](int i) {  // i < total (wave-uniform): the bucket whose range holds position i
-            const int b = __popcll(__ballot(lane < kBuckets && i >= bucket_end));
-            const int first = __builtin_amdgcn_readlane(bucket_start, b);
-            return queue_q + (size_t)b * p.qcap + (i - first);
+            const int l = lane_now();
+            const int b = __popcll(__ballot(l < kBuckets && i >= L.bucket_end[l & 31]));
+            const int first = b > 0 ? L.bucket_end[b - 1] : 0;
+            return queue_q + (size_t)b * p.qcap + (i - __builtin_amdgcn_readfirstlane(first));
         };
         unsigned *order_l = reinterpret_cast<unsigned *>(L.keys);
         typedef __attribute__((address_space(3))) const unsigned lds_u32;
@@ -1438,10 +1478,11 @@ __global__ __launch_bounds__(64, kRenderWavesPerSimd) void render_kernel(Params 
         const unsigned lists_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)&L.keys[kSortCap / 2];
         const unsigned null_slot = stage_base + (unsigned)kNullSlot * 16u;
         auto write_null_record = [&]() {  // log2(opacity) = -inf blends nothing
-            if (lane == 0) {
-                L.geo[kNullSlot] = make_float4(0.f, 0.f, 0.f, 0.f);
-                L.col[kNullSlot] = make_float4(0.f, 0.f, 0.f, 0.f);
-                L.geo2[kNullSlot] = make_float4(0.f, -__builtin_inff(), 0.f, 0.f);
+            if (lane_now() == 0) {
+                const float z = __uint_as_float(zero_now());
+                L.geo[kNullSlot] = make_float4(z, z, z, z);
+                L.col[kNullSlot] = make_float4(z, z, z, z);
+                L.geo2[kNullSlot] = make_float4(z, -__builtin_inff(), z, z);
             }
         };
         write_null_record();
@@ -1459,7 +1500,7 @@ __global__ __launch_bounds__(64, kRenderWavesPerSimd) void render_kernel(Params 
         int4 e_next = make_int4(0, 0, 0, 0);
         if (i_next < total) e_next = *entry_of(i_next);
         for (;;) {
-            const int ln = opaque(lane);  // per-tile copy of the lane id (see opaque())
+            const int ln = lane_now();  // per-tile copy of the lane id (see opaque(), lane_now())
             // the position after next: the atomic's round trip hides under this tile
             int idx2 = 0;
             if (ln == 0) idx2 = stride + atomicAdd(next, 1);
@@ -1757,7 +1798,7 @@ __global__ __launch_bounds__(64, kRenderWavesPerSimd) void render_kernel(Params 
     // the rest of this wave's background tiles (all of them when it had no tile to blend; every tile of the launch
     // when the instance regions overflowed: the caller must retry)
 #if AMAV_ABLATE != 5 && AMAV_ABLATE != 7
-    fill_some<kInvDepth>(p, fill, 0x7fffffff, lane);
+    fill_some<kInvDepth>(p, fill, 0x7fffffff, lane_now());
 #endif
 }
 
