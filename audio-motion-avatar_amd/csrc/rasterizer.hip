@@ -801,11 +801,7 @@ __global__ __launch_bounds__(256) void sort_big_kernel(Params p) {
                 const unsigned d = (unsigned)(k[m] >> 32);
                 if (in) dmin = min(dmin, d), dmax = max(dmax, d);
             }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                dmin = min(dmin, (unsigned)__shfl_xor((int)dmin, o, 64));
-                dmax = max(dmax, (unsigned)__shfl_xor((int)dmax, o, 64));
-            }
+            dmin = wave_min_u32(dmin), dmax = wave_max_u32(dmax);
             if (lane == 0) part[wave] = dmin, part[4 + wave] = dmax;
 #pragma unroll
             for (int i = 0; i < 4; ++i) cnt[tid + 256 * i] = 0u;
@@ -837,14 +833,8 @@ __global__ __launch_bounds__(256) void sort_big_kernel(Params p) {
                 c[i] = tot;
                 tot += ci;
             }
-            unsigned incl = tot;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const unsigned up = (unsigned)__shfl_up((int)incl, o, 64);
-                if (lane >= o) incl += up;
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) big = max(big, (unsigned)__shfl_xor((int)big, o, 64));
+            const unsigned incl = wave_inclusive_sum_u32(tot, lane);
+            big = wave_max_u32(big);
             __syncthreads();  // everyone has read part[] and its counters
             if (lane == 63) part[wave] = incl;
             if (lane == 0) part[4 + wave] = big;
