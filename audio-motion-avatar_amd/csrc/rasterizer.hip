@@ -1201,6 +1201,12 @@ __device__ __forceinline__ bool blend_quadrant(unsigned list, int groups, float 
         if (p.stamps && lane == 0) p.stamps[(size_t)item * 6 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
 
+typedef float nt_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_nt(float *rgba, long long pid, float4 v) {  // write-once output: non-temporal
+    const nt_f4 x = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(x, reinterpret_cast<nt_f4 *>(rgba) + pid);
+}
+
 // Background for the tiles without Gaussians: colour = bg, alpha = 0 (and inverse depth 0).  A wave owns the slice
 // [e0, e1) of the empty list and writes it a few tiles at a time between its blended tiles.  The tile ids are fetched
 // 64 at a time (one per lane) and decoded in the lanes, so a tile costs two scalar reads of lane registers and its
@@ -1255,7 +1261,7 @@ __device__ __forceinline__ void fill_some(const Params &p, FillCursor &c, int co
             for (int k = 0; k < 4; ++k) {
                 if (in_x && Y0 + cy + 4 * k < p.H) {
                     const long long pid = origin + (long long)(cy + 4 * k) * p.W + cx;
-                    reinterpret_cast<float4 *>(p.out_rgba)[pid] = px_bg;
+                    store_nt(p.out_rgba, pid, px_bg);
                     if (kInvDepth) p.out_inv_depth[pid] = 0.0f;
                 }
             }
@@ -1285,7 +1291,7 @@ __device__ __forceinline__ void fill_tile_at(const Params &p, FillCursor &c, int
     for (int k = 0; k < 4; ++k) {
         if (in_x && Y0 + cy + 4 * k < p.H) {
             const long long pid = origin + (long long)(cy + 4 * k) * p.W + cx;
-            reinterpret_cast<float4 *>(p.out_rgba)[pid] = make_float4(r, g, bl, 0.0f);
+            store_nt(p.out_rgba, pid, make_float4(r, g, bl, 0.0f));
             if (kInvDepth) p.out_inv_depth[pid] = 0.0f;
         }
     }
@@ -1742,7 +1748,7 @@ __global__ __launch_bounds__(64, kRenderWavesPerSimd) void render_kernel(Params 
                             bl = fminf(fmaxf(bl, 0.f), 1.f);
                         }
                         const size_t pid = ((size_t)f * p.H + py) * p.W + px;
-                        reinterpret_cast<float4 *>(p.out_rgba)[pid] = make_float4(r, g, bl, 1.0f - Tq[qd]);
+                        store_nt(p.out_rgba, pid, make_float4(r, g, bl, 1.0f - Tq[qd]));
                         if (kInvDepth) p.out_inv_depth[pid] = Dq[qd];
                     }
                 }
