@@ -87,6 +87,129 @@ static const Plan *plan_for(long long rows, int n, int k3, int index, size_t ws_
     return slot.ok && slot.workspace <= ws_bytes ? &slot : nullptr;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Hand-written form of the same product (algo_index = -2): the K-concatenated operands a = [h2 | h1 | h1], w = [g1 | g2 | g1]
+// hold each part once in their first two thirds, so the kernel stages h1, h2, g1, g2 once per K-step and issues the three
+// partial products h2 g1 + h1 g2 + h1 g1 per fragment pair -- the library GEMM over K' = 3K reads h1 and g1 twice.
+// Block = 256 threads = 2 x 2 waves, tile 128 x 128, K-step 32; a wave owns 64 x 64 = 2 x 2 v_mfma_f32_32x32x16_f16 tiles
+// (64 accumulator registers).  LDS: [part][row][32 halfs] with the 16-byte chunk index XOR-ed by (row >> 2) & 3, so the
+// sixteen lanes of a ds_read_b128 pass (sixteen consecutive rows, one chunk column) hit sixteen different bank quads;
+// two stages of 32 KB; the next stage's 16-byte global loads are in flight under the current stage's 24 MFMAs per wave.
+// Status (tools/bench_split_gemm.py, 6304 rows): correct to the library's own distance from fp64 (6e-7 of the largest
+// output), 440-715 TFLOP/s issued against the tuned library kernels' 550-915 -- the matrix pipe waits for LDS fragment reads
+// between small groups of MFMAs and for a barrier per 32 of K (all fragments first + accumulators in turn: no better).
+// Not on the product path: a base for the fused forms (GEGLU gate in the epilogue, next operand split in the epilogue)
+// that a library GEMM cannot express.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kBM = 128, kBN = 128, kBK = 32;
+constexpr int kStageBytes = 2 * (kBM + kBN) * kBK * 2;  // both parts of both operands: 32 KB
+
+__device__ __forceinline__ int lds_chunk_offset(int row, int chunk) {  // bytes inside one part's [rows][32 halfs] block
+    return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4);
+}
+
+__global__ __launch_bounds__(256, 2) void split_gemm_kernel(long long M, int N, int K, const _Float16 *__restrict__ A,
+                                                            const _Float16 *__restrict__ W, float alpha, float *__restrict__ out) {
+    extern __shared__ __align__(16) unsigned char gemm_lds[];  // [stage][A h1 | A h2 | W g1 | W g2] each kBM (kBN) x 64 B
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    // block -> tile: consecutive blocks walk down M inside one column of tiles, so the 128 weight rows of the column
+    // stay in L2 while the activations stream
+    const int tiles_m = (int)((M + kBM - 1) / kBM);
+    const int bm = blockIdx.x % tiles_m, bn = blockIdx.x / tiles_m;
+    const long long m0 = (long long)bm * kBM;
+    const int n0 = bn * kBN;
+    const size_t lda = (size_t)3 * K;  // halfs per row of both operands
+    // staging: 512 chunks of 16 B per part and operand = 2 per thread; thread t handles rows (t >> 2) and (t >> 2) + 64,
+    // chunk t & 3
+    const int srow = tid >> 2, schunk = tid & 3;
+    const _Float16 *a_src[2], *w_src[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const long long r = min(m0 + srow + 64 * i, M - 1);  // rows past M: a valid row is read, its results never stored
+        a_src[i] = A + (size_t)r * lda + schunk * 8;
+        w_src[i] = W + (size_t)(n0 + srow + 64 * i) * lda + schunk * 8;
+    }
+    u32x4 st[8];  // [operand part][i]: A h2 (cols 0..K), A h1 (K..2K), W g1 (0..K), W g2 (K..2K)
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            st[0 + i] = *reinterpret_cast<const u32x4 *>(a_src[i] + k0);
+            st[2 + i] = *reinterpret_cast<const u32x4 *>(a_src[i] + K + k0);
+            st[4 + i] = *reinterpret_cast<const u32x4 *>(w_src[i] + k0);
+            st[6 + i] = *reinterpret_cast<const u32x4 *>(w_src[i] + K + k0);
+        }
+    };
+    auto lstore = [&](int stage) {
+        unsigned char *base = gemm_lds + stage * kStageBytes;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int off = lds_chunk_offset(srow + 64 * i, schunk);
+            *reinterpret_cast<u32x4 *>(base + 0 * kBM * 64 + off) = st[0 + i];                 // A h2
+            *reinterpret_cast<u32x4 *>(base + 1 * kBM * 64 + off) = st[2 + i];                 // A h1
+            *reinterpret_cast<u32x4 *>(base + 2 * kBM * 64 + 0 * kBN * 64 + off) = st[4 + i];  // W g1
+            *reinterpret_cast<u32x4 *>(base + 2 * kBM * 64 + 1 * kBN * 64 + off) = st[6 + i];  // W g2
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int frow = lane & 31, fh = lane >> 5;  // fragment: row (column) inside the 32-tile, k half
+    const int nsteps = K / kBK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        if (s + 1 < nsteps) gload((s + 1) * kBK);
+        const unsigned char *base = gemm_lds + (s & 1) * kStageBytes;
+        const unsigned char *a2p = base, *a1p = base + kBM * 64, *b1p = base + 2 * kBM * 64, *b2p = b1p + kBN * 64;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            f16x8 a1[2], a2[2], b1[2], b2[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int ra = wm * 64 + i * 32 + frow, rb = wn * 64 + i * 32 + frow;
+                const int oa = lds_chunk_offset(ra, ks * 2 + fh), ob = lds_chunk_offset(rb, ks * 2 + fh);
+                a2[i] = *reinterpret_cast<const f16x8 *>(a2p + oa);
+                a1[i] = *reinterpret_cast<const f16x8 *>(a1p + oa);
+                b1[i] = *reinterpret_cast<const f16x8 *>(b1p + ob);
+                b2[i] = *reinterpret_cast<const f16x8 *>(b2p + ob);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2[i], b1[j], acc[i][j], 0, 0, 0);  // small terms first
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[i], b2[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[i], b1[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        if (s + 1 < nsteps) lstore((s + 1) & 1);  // the other buffer: last read in step s - 1, behind the barrier below
+        __syncthreads();
+    }
+    // accumulator register r of lane (frow, fh) of tile (i, j): row 8 (r >> 2) + 4 fh + (r & 3), column frow
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long m = m0 + wm * 64 + i * 32 + 8 * (r >> 2) + 4 * fh + (r & 3);
+                if (m < M) out[(size_t)m * N + n0 + wn * 64 + j * 32 + frow] = alpha * acc[i][j][r];
+            }
+}
+
+static bool split_gemm_supported(long long rows, int n, int k3) {
+    return k3 % 3 == 0 && (k3 / 3) % kBK == 0 && n % kBN == 0 && rows > 0 && (rows + kBM - 1) / kBM * (long long)(n / kBN) < (1ll << 31);
+}
+
 }  // namespace gemm
 }  // namespace amav
 
@@ -104,6 +227,17 @@ static int check_gemm_args(const char *who, int64_t rows, int n, int k3, const v
 extern "C" int amav_gemm_split_fp16(int64_t rows, int n, int k3, const void *a, const void *w, float alpha, float *out,
                                     int algo_index, void *workspace, size_t workspace_bytes, void *stream) {
     if (int rc = check_gemm_args("amav_gemm_split_fp16", rows, n, k3, a, w, out)) return rc;
+    if (algo_index == -2) {  // the hand-written kernel
+        AMAV_REQUIRE(gemm::split_gemm_supported(rows, n, k3), "amav_gemm_split_fp16: the hand-written kernel needs n %% 128 == 0 and "
+                     "k3 = 3 K with K %% 32 == 0 (rows=%lld n=%d k3=%d)", (long long)rows, n, k3);
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm::split_gemm_kernel),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * gemm::kStageBytes);
+        if (attr != hipSuccess) return fail(AMAV_ERR_LAUNCH, "amav_gemm_split_fp16: cannot raise the dynamic LDS limit");
+        const unsigned blocks = (unsigned)((rows + gemm::kBM - 1) / gemm::kBM * (n / gemm::kBN));
+        gemm::split_gemm_kernel<<<blocks, 256, 2 * gemm::kStageBytes, static_cast<hipStream_t>(stream)>>>(
+            rows, n, k3 / 3, static_cast<const _Float16 *>(a), static_cast<const _Float16 *>(w), alpha, out);
+        return check_launch("amav_gemm_split_fp16");
+    }
     const gemm::Plan *p = gemm::plan_for(rows, n, k3, algo_index, workspace ? workspace_bytes : 0);
     if (!p) return fail(AMAV_ERR_LAUNCH, "amav_gemm_split_fp16: hipBLASLt has no kernel for rows=%lld n=%d k=%d within %zu B of workspace",
                         (long long)rows, n, k3, workspace_bytes);

@@ -454,7 +454,9 @@ int amav_unpool_merge(int64_t rows, int channels, const float *x_dev, const floa
  * w[n, k3]^T with fp16 operands and fp32 accumulation -- the three partial products of an fp32-equivalent nn.Linear
  * (src/models/transformers.py:70-84, 448, 505) concatenated along K.  hipBLASLt does the arithmetic; `algo_index` names
  * one of its kernels (as found by amav_gemm_split_fp16_tune for this shape on this library build), -1 or an index the
- * library does not accept selects its own heuristic's choice.  `workspace` may be NULL for kernels that need none.
+ * library does not accept selects its own heuristic's choice; -2 runs this library's own kernel instead (n % 128 == 0,
+ * k3 = 3 K with K % 32 == 0, operands laid out [h2 | h1 | h1] and [g1 | g2 | g1]: it reads the first two thirds and issues
+ * the three partial products itself; correct, 70-80 % of the tuned library kernels' speed, not on the product path).  `workspace` may be NULL for kernels that need none.
  * amav_gemm_split_fp16_tune synchronises: it times every kernel of the library on the given operands (`repeats` runs
  * each; with `copies` > 1 the three buffers hold that many consecutive operand sets and run i uses set i % copies, which
  * times a kernel as it runs inside the step, not out of a hot L2) and reports the fastest one's index and time next to

@@ -267,3 +267,29 @@ def test_library_gemm_entry_equals_torch_for_every_selectable_kernel(rows, n, k3
     assert ops.gemm_library_version().startswith("hipblaslt-")
     with pytest.raises(ops.AmavError):
         ops.gemm_split_fp16(a[:, :-4].contiguous(), w[:, :-4].contiguous())   # k3 not a multiple of 8
+
+
+@pytest.mark.parametrize("rows,n,k", [(6304, 512, 2048), (6304, 1536, 512), (200, 128, 64), (129, 256, 32)])
+def test_hand_written_split_gemm_kernel_matches_the_library_product(rows, n, k):
+    """algo_index = -2 (csrc/gemm.hip, split_gemm_kernel): the same fp32-equivalent product from the K-concatenated
+    operands a = [h2 | h1 | h1], w = [g1 | g2 | g1], staging each part once and issuing h2 g1 + h1 g2 + h1 g1 per
+    fragment pair.  Partial row tiles (6304 = 49 x 128 + 32; 129, 200), several K depths; against fp64 of the split
+    operands and against the library GEMM over K' = 3K."""
+    from audio_motion_avatar_amd import ops
+
+    g = torch.Generator(device="cuda").manual_seed(rows + n + k)
+    h = torch.randn(rows, k, device="cuda", generator=g) * 3.0
+    w = torch.randn(n, k, device="cuda", generator=g) * 2.0
+    h1, w1 = h.half(), w.half()
+    h2, w2 = (h - h1.float()).half(), (w - w1.float()).half()
+    a = torch.cat([h2, h1, h1], dim=1).contiguous()
+    b = torch.cat([w1, w2, w1], dim=1).contiguous()
+    ref = 0.5 * ((h1.double() + h2.double()) @ (w1.double() + w2.double()).t() - h2.double() @ w2.double().t())
+    scale = float(ref.abs().max())
+    got = ops.gemm_split_fp16(a, b, 0.5, -2)
+    lib = ops.gemm_split_fp16(a, b, 0.5, -1)
+    assert got.shape == (rows, n)
+    assert float((got.double() - ref).abs().max()) <= 2e-6 * scale
+    assert float((got - lib).abs().max()) <= 2e-6 * scale
+    with pytest.raises(ops.AmavError):
+        ops.gemm_split_fp16(a, b[:100].contiguous(), 1.0, -2)   # n not a multiple of 128
