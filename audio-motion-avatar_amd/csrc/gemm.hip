@@ -97,8 +97,10 @@ static const Plan *plan_for(long long rows, int n, int k3, int index, size_t ws_
 // sixteen lanes of a ds_read_b128 pass (sixteen consecutive rows, one chunk column) hit sixteen different bank quads;
 // two stages of 32 KB; the next stage's 16-byte global loads are in flight under the current stage's 24 MFMAs per wave.
 // Status (tools/bench_split_gemm.py, 6304 rows): correct to the library's own distance from fp64 (6e-7 of the largest
-// output), 440-715 TFLOP/s issued against the tuned library kernels' 550-915 -- the matrix pipe waits for LDS fragment reads
-// between small groups of MFMAs and for a barrier per 32 of K (all fragments first + accumulators in turn: no better).
+// output), 470-715 TFLOP/s issued against the tuned library kernels' 510-930 -- the matrix pipe waits for LDS fragment reads
+// between small groups of MFMAs and for a barrier per 32 of K (matrix pipe 38 % busy by SQ_VALU_MFMA_BUSY_CYCLES, the library's
+// kernels 48 %; all sixteen fragments of a K-step requested before its first MFMA: slower, 62 vs 54 us; the four
+// accumulators in turn: no change).
 // Not on the product path: a base for the fused forms (GEGLU gate in the epilogue, next operand split in the epilogue)
 // that a library GEMM cannot express.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -133,8 +135,13 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(long long M, int N, 
         a_src[i] = A + (size_t)r * lda + schunk * 8;
         w_src[i] = W + (size_t)(n0 + srow + 64 * i) * lda + schunk * 8;
     }
-    u32x4 st[8];  // [operand part][i]: A h2 (cols 0..K), A h1 (K..2K), W g1 (0..K), W g2 (K..2K)
-    auto gload = [&](int k0) {
+    // Two register sets of staged chunks: the global loads of K-step s + 2 are issued at the top of step s and stored to
+    // LDS at the end of step s + 1 (one step of MFMAs, ~0.6 us, is shorter than a global round trip: with the loads one
+    // step ahead the K = 2048 projection ran 74 us, with two 66).
+    u32x4 st0[8], st1[8];  // [operand part][i]: A h2 (cols 0..K), A h1 (K..2K), W g1 (0..K), W g2 (K..2K)
+    const int nsteps = K / kBK;
+    auto gload = [&](u32x4 (&st)[8], int step) {
+        const int k0 = min(step, nsteps - 1) * kBK;  // past the end: the last step again (never stored)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             st[0 + i] = *reinterpret_cast<const u32x4 *>(a_src[i] + k0);
@@ -143,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(long long M, int N, 
             st[6 + i] = *reinterpret_cast<const u32x4 *>(w_src[i] + K + k0);
         }
     };
-    auto lstore = [&](int stage) {
+    auto lstore = [&](const u32x4 (&st)[8], int stage) {
         unsigned char *base = gemm_lds + stage * kStageBytes;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -162,13 +169,8 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(long long M, int N, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const int frow = lane & 31, fh = lane >> 5;  // fragment: row (column) inside the 32-tile, k half
-    const int nsteps = K / kBK;
-    gload(0);
-    lstore(0);
-    __syncthreads();
-    for (int s = 0; s < nsteps; ++s) {
-        if (s + 1 < nsteps) gload((s + 1) * kBK);
-        const unsigned char *base = gemm_lds + (s & 1) * kStageBytes;
+    auto compute = [&](int stage) {
+        const unsigned char *base = gemm_lds + stage * kStageBytes;
         const unsigned char *a2p = base, *a1p = base + kBM * 64, *b1p = base + 2 * kBM * 64, *b2p = b1p + kBN * 64;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -191,7 +193,20 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(long long M, int N, 
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[i], b1[j], acc[i][j], 0, 0, 0);
                 }
         }
-        if (s + 1 < nsteps) lstore((s + 1) & 1);  // the other buffer: last read in step s - 1, behind the barrier below
+    };
+    gload(st0, 0);
+    gload(st1, 1);
+    lstore(st0, 0);
+    __syncthreads();
+    for (int s = 0; s < nsteps; s += 2) {
+        gload(st0, s + 2);
+        compute(0);
+        if (s + 1 < nsteps) lstore(st1, 1);  // stage 1 was last read in step s - 1, behind the barrier that ended it
+        __syncthreads();
+        if (s + 1 >= nsteps) break;
+        gload(st1, s + 3);
+        compute(1);
+        if (s + 2 < nsteps) lstore(st0, 0);
         __syncthreads();
     }
     // accumulator register r of lane (frow, fh) of tile (i, j): row 8 (r >> 2) + 4 fh + (r & 3), column frow
