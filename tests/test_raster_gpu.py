@@ -79,7 +79,9 @@ def compare(scene, out, tol=TOL, **settings):
     return ref
 
 
-@pytest.mark.parametrize("N,H,W,F", [(300, 64, 80, 1), (2000, 256, 256, 2), (500, 50, 70, 3), (64, 16, 16, 1)])
+@pytest.mark.parametrize("N,H,W,F", [(300, 64, 80, 1), (2000, 256, 256, 2), (500, 50, 70, 3), (64, 16, 16, 1),
+                                     (150, 48, 64, 40),   # 40 frames: binning in 7 slices per frame (bin_slices)
+                                     (90, 32, 48, 97)])   # >= 96 frames: the fused per-frame binning block
 def test_random_scenes(N, H, W, F):
     scene = random_scene(1234 + N, N, H, W, F)
     compare(scene, run_hip(scene))
