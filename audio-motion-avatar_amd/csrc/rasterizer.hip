@@ -131,6 +131,7 @@ struct Params {
     unsigned char *wire_payload;
     int wire_cap;
     unsigned wire_bg;
+    int stash;   // fused binning: the binning records of the frame also go to LDS (8 B each) for the key scatter
     int slices;  // few-frame shards: blocks per frame of slice_count_kernel / slice_scatter_kernel (bin_slices)
     Buffers buf;
 };
@@ -411,6 +412,7 @@ __global__ __launch_bounds__(1024) void bin_kernel(Params p) {
     int *counts = bin_lds;
     int *cursor = bin_lds + p.T;
     int *scratch = bin_lds + 2 * p.T + 3 * kQueues * (kBuckets + 1);
+    uint2 *stash = reinterpret_cast<uint2 *>(scratch + 48);  // [N] when p.stash (8-byte aligned: 2 T + 480 ints in front)
     const int f = blockIdx.x;
 #ifdef AMAV_BIN_STAMPS  /* diagnostic build (tools/stamp_bin.sh): block-level phase stamps behind the blend kernel's */
 #define AMAV_BIN_STAMP(k)                                                                                        \
@@ -459,6 +461,8 @@ __global__ __launch_bounds__(1024) void bin_kernel(Params p) {
                     for (int tx = rx0; tx < rx1; ++tx) atomicAdd(&counts[ty * p.gx + tx], 1);
             }
 #endif
+            if (p.stash && real)  // tile box (8 bits per bound) + depth bits: what the key scatter needs, without a reload
+                stash[i] = make_uint2((rd.x & 0xff) | ((rd.x >> 16) << 8) | ((rd.y & 0xff) << 16) | ((rd.y >> 16) << 24), rd.z);
             const size_t gi = real ? (size_t)f * p.N + i : (size_t)p.F * p.N + threadIdx.x;  // spare slots: carve()
             p.buf.rectd[gi] = rd;
             float4 *dst = p.buf.geom + gi * 3;
@@ -595,6 +599,19 @@ __global__ __launch_bounds__(1024) void bin_kernel(Params p) {
     // key store: a load issued after the key stores of the previous Gaussian would wait for their acknowledgement
     // (in-order vector memory, see phase 1) once per Gaussian; this way once per chunk, i.e. not at all up to 12 288
     // Gaussians per frame.
+    if (kFused && p.stash) {
+        // the frame's binning records are in LDS (written by phase 1): no reload -- a load here would first wait for
+        // the acknowledgement of phase 2's stores (queues, offsets: 12 of this pass's 36 us)
+        for (int i = threadIdx.x; i < p.N; i += blockDim.x) {
+            const uint2 e = stash[i];
+            const int rx0 = e.x & 0xff, ry0 = (e.x >> 8) & 0xff, rx1 = (e.x >> 16) & 0xff, ry1 = e.x >> 24;
+            const unsigned long long key = ((unsigned long long)e.y << 32) | (unsigned)i;
+            for (int ty = ry0; ty < ry1; ++ty)
+                for (int tx = rx0; tx < rx1; ++tx) keys[atomicAdd(&cursor[ty * p.gx + tx], 1)] = key;
+        }
+        AMAV_BIN_STAMP(4);
+        return;
+    }
     const uint4 *rect = p.buf.rectd + (size_t)f * p.N;
     constexpr int kScatterChunk = 12;
     for (int base = threadIdx.x; base < p.N; base += kScatterChunk * (int)blockDim.x) {
@@ -1854,6 +1871,9 @@ extern "C" int amav_rasterize_forward(const amav_raster_args *a, void *stream_) 
     const size_t bin_lds = ((size_t)2 * T + 48 + 3 * kQueues * (kBuckets + 1)) * sizeof(int);
     AMAV_REQUIRE(bin_lds <= 160 * 1024, "amav_rasterize_forward: %d tiles need %zu B of LDS in the binning block (max 160 KiB)",
                  T, bin_lds);
+    // fused binning: room in LDS for the frame's binning records (8 B each), tile bounds in 8 bits, no radii output
+    // (the scatter pass writes those from the full records)
+    const bool stash = bin_lds + 8 + (size_t)N * 8 <= 160 * 1024 && gx <= 255 && gy <= 255 && a->out_radii == nullptr;
     const long long cap_per_frame = a->instance_capacity / F;
     AMAV_REQUIRE(cap_per_frame < (1ll << 31), "amav_rasterize_forward: per-frame instance capacity overflows int32");
     size_t need = 0;
@@ -1877,6 +1897,7 @@ extern "C" int amav_rasterize_forward(const amav_raster_args *a, void *stream_) 
     p.wire_header = nullptr, p.wire_frame_counts = nullptr, p.wire_offsets = nullptr, p.wire_payload = nullptr;
     p.wire_cap = 0, p.wire_bg = 0;
     p.slices = bin_slices(F);
+    p.stash = stash ? 1 : 0;
     if (a->wire) {
         AMAV_REQUIRE(a->clamp_output, "amav_rasterize_forward: the wire output carries the clamped colours (set clamp_output)");
         AMAV_REQUIRE((reinterpret_cast<uintptr_t>(a->wire) & 15) == 0 && a->wire_capacity_tiles >= 0 &&
@@ -1934,9 +1955,9 @@ extern "C" int amav_rasterize_forward(const amav_raster_args *a, void *stream_) 
         bin_kernel<false, false><<<F, 1024, bin_lds, stream>>>(p);
         slice_scatter_kernel<<<slice_grid, 1024, (size_t)T * sizeof(int), stream>>>(p);
     } else if (packed)
-        bin_kernel<true, true><<<F, 1024, bin_lds, stream>>>(p);
+        bin_kernel<true, true><<<F, 1024, bin_lds + (stash ? 8 + (size_t)N * 8 : 0), stream>>>(p);
     else
-        bin_kernel<true, false><<<F, 1024, bin_lds, stream>>>(p);
+        bin_kernel<true, false><<<F, 1024, bin_lds + (stash ? 8 + (size_t)N * 8 : 0), stream>>>(p);
     sort_big_kernel<<<kBigBlocks, 256, 0, stream>>>(p);
     // persistent grid: the waves the chip holds at once (a multiple of kQueues)
     const unsigned blocks = render_grid(a->out_inv_depth != nullptr);
