@@ -181,6 +181,10 @@ SIGNATURES = {
                                                      c_float_p, c_float_p, ctypes.c_int64, c_float_p, ctypes.c_int64,
                                                      ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                                      ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "amav_selfattn_forward_split_out": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_float_p,
+                                                     c_float_p, c_float_p, ctypes.c_int64, c_float_p, ctypes.c_int64,
+                                                     ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                                     ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
 }
 
 _lib = None

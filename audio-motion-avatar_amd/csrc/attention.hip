@@ -198,9 +198,14 @@ __global__ __launch_bounds__(256, 3) void selfattn_kernel(const float *__restric
     }
 }
 
-// One thread per (b, head, query, 4 consecutive d): merge the nsplit partial softmax states.
+// One thread per (b, head, query, 4 consecutive d): merge the nsplit partial softmax states.  kSplitOut: the result goes
+// out as the fp16 x 2 operand of the projection that follows (rows of [h2 | h1 | h1], K = H * 64 each, x 2^scale_exp =
+// h1 + h2: exactly what split_operand_f16_kernel makes of the fp32 result, without the pass over it).
+typedef _Float16 c_f16x4 __attribute__((ext_vector_type(4)));
+template <bool kSplitOut>
 __global__ __launch_bounds__(256) void combine_kernel(const float *__restrict__ part, float *__restrict__ out, int B,
-                                                      int H, int S, int nsplit, long long out_row_stride) {
+                                                      int H, int S, int nsplit, long long out_row_stride,
+                                                      _Float16 *__restrict__ out_split, float prescale) {
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int d4 = (int)(gid & 15);
     const long long row = gid >> 4;  // (b * H + head) * S + query
@@ -218,6 +223,22 @@ __global__ __launch_bounds__(256) void combine_kernel(const float *__restrict__ 
     }
     const float inv = 1.0f / l;
     const int qi = (int)(row % S), head = (int)((row / S) % H), b = (int)(row / ((long long)S * H));
+    if (kSplitOut) {
+        const float v[4] = {o0 * inv, o1 * inv, o2 * inv, o3 * inv};
+        c_f16x4 p1, p2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float x = v[j] * prescale;
+            const _Float16 a = (_Float16)x;
+            p1[j] = a, p2[j] = (_Float16)__builtin_fmaf((float)a, -1.0f, x);
+        }
+        const size_t K = (size_t)H * kD;
+        _Float16 *dst = out_split + ((size_t)b * S + qi) * 3 * K + head * kD + 4 * d4;
+        *reinterpret_cast<c_f16x4 *>(dst) = p2;
+        *reinterpret_cast<c_f16x4 *>(dst + K) = p1;
+        *reinterpret_cast<c_f16x4 *>(dst + 2 * K) = p1;
+        return;
+    }
     float *orow = out + ((size_t)b * S + qi) * out_row_stride + head * kD + 4 * d4;
     *reinterpret_cast<float4 *>(orow) = make_float4(o0 * inv, o1 * inv, o2 * inv, o3 * inv);
 }
@@ -924,6 +945,17 @@ extern "C" int amav_selfattn_forward_bounded(int B, int S, int H, int D, const f
                                              int64_t row_stride, float *out, int64_t out_row_stride, float scale,
                                              float q_bound, float k_bound, float v_bound, void *workspace,
                                              size_t workspace_bytes, void *stream_) {
+    return amav_selfattn_forward_split_out(B, S, H, D, q, k, v, row_stride, out, out_row_stride, scale, q_bound, k_bound, v_bound,
+                                           nullptr, 0, workspace, workspace_bytes, stream_);
+}
+
+extern "C" int amav_selfattn_forward_split_out(int B, int S, int H, int D, const float *q, const float *k, const float *v,
+                                               int64_t row_stride, float *out, int64_t out_row_stride, float scale,
+                                               float q_bound, float k_bound, float v_bound, void *out_split,
+                                               int split_scale_exp, void *workspace, size_t workspace_bytes, void *stream_) {
+    AMAV_REQUIRE(out_split == nullptr || ((reinterpret_cast<uintptr_t>(out_split) & 15) == 0 && split_scale_exp >= -126 &&
+                                          split_scale_exp <= 126 && out_row_stride == (int64_t)H * D),
+                 "amav_selfattn_forward_split_out: out_split must be 16-byte aligned, |scale_exp| <= 126, out rows dense");
     const bool bounded = q_bound > 0.f && k_bound > 0.f && v_bound > 0.f;
     AMAV_REQUIRE(bounded || (q_bound == 0.f && k_bound == 0.f && v_bound == 0.f),
                  "amav_selfattn_forward_bounded: give all three bounds (> 0, finite) or none (0)");
@@ -987,8 +1019,16 @@ extern "C" int amav_selfattn_forward_bounded(int B, int S, int H, int D, const f
                                                         scale * 1.4426950408889634f, ns, static_cast<float *>(workspace));
     if (ns > 1) {
         const long long threads = (long long)B * H * S * 16;
-        attn::combine_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, stream>>>(static_cast<const float *>(workspace),
-                                                                                    out, B, H, S, ns, out_row_stride);
+        if (out_split)  // the partial states are merged straight into the next projection's fp16 x 2 operand
+            attn::combine_kernel<true><<<(unsigned)((threads + 255) / 256), 256, 0, stream>>>(
+                static_cast<const float *>(workspace), out, B, H, S, ns, out_row_stride, static_cast<_Float16 *>(out_split),
+                std::ldexp(1.0f, split_scale_exp));
+        else
+            attn::combine_kernel<false><<<(unsigned)((threads + 255) / 256), 256, 0, stream>>>(
+                static_cast<const float *>(workspace), out, B, H, S, ns, out_row_stride, nullptr, 1.0f);
+    } else if (out_split) {  // one key slice: the kernel wrote `out`; split it as amav_split_operand would
+        if (int rc = check_launch("amav_selfattn_forward")) return rc;
+        return amav_split_operand((int64_t)B * S, H * D, out, out_row_stride, 0, AMAV_SPLIT_FP16X2, split_scale_exp, out_split, stream_);
     }
     return check_launch("amav_selfattn_forward");
 }

@@ -657,10 +657,12 @@ def points_project(points, w2c, intrinsics, features, radius_px):
 ATTN_PROFILE_EVENTS = None
 
 
-def selfattn(q, k, v, heads, scale=None, bounds=None):
+def selfattn(q, k, v, heads, scale=None, bounds=None, split_out_exp=None):
     """softmax(q k^T * scale) v for [B,S,H*D] fp32 tensors (row stride may exceed H*D), D = 64.  bounds: (|q|, |k|, |v|)
     upper bounds the caller can prove, which spare the kernel its magnitude pre-pass (include/amav.h,
-    amav_selfattn_forward_bounded); None: measured."""
+    amav_selfattn_forward_bounded); None: measured.  split_out_exp: return instead the fp16 x 2 activation operand
+    [B*S, 3*H*D] of the projection that follows (split_operand(out, fmt=SPLIT_FP16X2, scale_exp=split_out_exp), written
+    by the kernel's own last pass: amav_selfattn_forward_split_out)."""
     for name, t in (("q", q), ("k", k), ("v", v)):
         _need(t, name)
         if t.dim() != 3 or t.stride(2) != 1 or t.stride(0) != t.shape[1] * t.stride(1):
@@ -678,13 +680,15 @@ def selfattn(q, k, v, heads, scale=None, bounds=None):
     if ev is not None:
         ev[0].record()
     qb, kb, vb = (float(x) for x in bounds) if bounds is not None else (0.0, 0.0, 0.0)
-    check(_lib.lib().amav_selfattn_forward_bounded(B, S, heads, D, q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(1),
-                                                   out.data_ptr(), HD, float(scale if scale is not None else D ** -0.5),
-                                                   qb, kb, vb, ws.data_ptr(), nbytes, _stream()),
-          "amav_selfattn_forward_bounded")
+    split = None if split_out_exp is None else _split_buffer(B * S, HD, SPLIT_FP16X2, q.device)
+    check(_lib.lib().amav_selfattn_forward_split_out(B, S, heads, D, q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(1),
+                                                     out.data_ptr(), HD, float(scale if scale is not None else D ** -0.5),
+                                                     qb, kb, vb, split.data_ptr() if split is not None else None,
+                                                     int(split_out_exp or 0), ws.data_ptr(), nbytes, _stream()),
+          "amav_selfattn_forward_split_out")
     if ev is not None:
         ev[1].record()
-    return out
+    return out if split is None else split
 
 
 _GEMM_WS = {}

@@ -157,11 +157,12 @@ class Attention(nn.Module):
         exponent of the attention output's proven bound, which sends to_out through the fp16 x 2 GEMM; bounds: proven
         (|q|, |k|, |v|) bounds for the kernel's operand scaling."""
         i = self.inner_dim
-        out = ops.selfattn(qkv[..., :i], qkv[..., i:2 * i], qkv[..., 2 * i:], self.heads, bounds=bounds)
         if out_exp is None:
+            out = ops.selfattn(qkv[..., :i], qkv[..., i:2 * i], qkv[..., 2 * i:], self.heads, bounds=bounds)
             return linear(out, self.to_out[0].weight, self.to_out[0].bias if out_bias else None)
-        a = ops.split_operand(out.view(-1, i), fmt=ops.SPLIT_FP16X2, scale_exp=out_exp)
-        y = gemm_fp16(a, out_exp, self.to_out[0].weight).view(*out.shape[:-1], -1)
+        # the kernel's last pass writes to_out's fp16 x 2 operand itself (no fp32 result, no split pass over it)
+        a = ops.selfattn(qkv[..., :i], qkv[..., i:2 * i], qkv[..., 2 * i:], self.heads, bounds=bounds, split_out_exp=out_exp)
+        y = gemm_fp16(a, out_exp, self.to_out[0].weight).view(*qkv.shape[:-1], -1)
         return y + self.to_out[0].bias if out_bias else y
 
     def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None):

@@ -339,6 +339,15 @@ int amav_selfattn_forward_bounded(int batch, int seq_len, int heads, int head_di
                                   const float *k_dev, const float *v_dev, int64_t row_stride, float *out_dev,
                                   int64_t out_row_stride, float scale, float q_bound, float k_bound, float v_bound,
                                   void *workspace, size_t workspace_bytes, void *stream);
+/* The same, with the result ALSO (or, when the key range is split over workgroups, ONLY) written as the fp16 x 2 activation
+ * operand of the projection that follows (amav_split_operand's AMAV_SPLIT_FP16X2 layout, rows of [h2 | h1 | h1] with K =
+ * heads * head_dim, x 2^split_scale_exp = h1 + h2): diffusers' to_out after the attention (transformers.py:329-336, 448).
+ * out_split_dev [batch * seq_len, 3 K] fp16, 16-byte aligned; out_dev rows dense (out_row_stride = K) -- whether out_dev is
+ * written depends on the key split the kernel chooses, so a caller that passes out_split must not read it.  NULL: as above. */
+int amav_selfattn_forward_split_out(int batch, int seq_len, int heads, int head_dim, const float *q_dev, const float *k_dev,
+                                    const float *v_dev, int64_t row_stride, float *out_dev, int64_t out_row_stride,
+                                    float scale, float q_bound, float k_bound, float v_bound, void *out_split_dev,
+                                    int split_scale_exp, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Operand of an fp32-equivalent nn.Linear (src/models/transformers.py:70-84, 448, 505: the to_q/k/v, to_out and
  * feed-forward projections) computed as ONE low-precision GEMM with fp32 accumulation over operands split into parts

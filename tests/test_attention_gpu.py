@@ -118,3 +118,24 @@ def test_selfattn_rejects_partial_bounds():
     x = torch.randn(1, 64, 64).cuda()
     with pytest.raises(AmavError):
         ops.selfattn(x, x, x, 1, bounds=(1.0, 0.0, 1.0))
+
+
+@pytest.mark.parametrize("B,S,H", [(1, 6304, 8), (1, 200, 2), (2, 777, 4)])
+def test_split_output_equals_the_split_of_the_fp32_result(B, S, H):
+    """amav_selfattn_forward_split_out: the kernel's last pass writes the next projection's fp16 x 2 operand ([h2 | h1 |
+    h1], x 2^e = h1 + h2) -- bit for bit what amav_split_operand makes of the fp32 result, with the key range split over
+    workgroups (6304 keys: the merge pass writes it) and without (200 keys: the library splits the result itself)."""
+    from audio_motion_avatar_amd import ops
+
+    g = torch.Generator(device="cuda").manual_seed(S + H)
+    qkv = torch.randn(B, S, 3 * H * 64, device="cuda", generator=g)
+    i = H * 64
+    q, k, v = qkv[..., :i], qkv[..., i:2 * i], qkv[..., 2 * i:]
+    bounds = (float(q.abs().max()) * 1.1, float(k.abs().max()) * 1.1, float(v.abs().max()) * 1.1)
+    exp = 9  # |out| <= max |v| < 8: 2^9 keeps h1 far inside fp16
+    want = ops.split_operand(ops.selfattn(q, k, v, H, bounds=bounds).view(-1, i), fmt=ops.SPLIT_FP16X2, scale_exp=exp)
+    got = ops.selfattn(q, k, v, H, bounds=bounds, split_out_exp=exp)
+    assert got.dtype == torch.float16 and tuple(got.shape) == (B * S, 3 * i)
+    assert torch.equal(got, want)
+    got2 = ops.selfattn(q, k, v, H, split_out_exp=exp)  # measured magnitudes
+    assert torch.equal(got2, ops.split_operand(ops.selfattn(q, k, v, H).view(-1, i), fmt=ops.SPLIT_FP16X2, scale_exp=exp))
