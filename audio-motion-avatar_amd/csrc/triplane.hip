@@ -455,7 +455,10 @@ extern "C" int amav_triplane_project_region(int F, int C, int R, const float *to
         // 786 MB slab: 140 us (5.6 TB/s) with the double-buffered loads at 4 channels per buffer (8: 149 us, 2: 145 us); the
         // single unrolled loop it replaces drained its loads at every trip and stopped at 216 us (3.6 TB/s).
         // AMAV_PROJECT_UNROLL = 2 / 4 / 8 is a tuning aid.
-        static const int unroll = getenv("AMAV_PROJECT_UNROLL") ? atoi(getenv("AMAV_PROJECT_UNROLL")) : 4;
+        // with a region and many channels the launch is a serial chain of C / unroll load groups per wave on a part of the
+        // chip: 8 per group there (32 x 3 x 128^2 x 512 channels: 0.273 -> 0.228 ms; 250 x 3 x 32^2 x 256: 4 is better)
+        static const int env_unroll = getenv("AMAV_PROJECT_UNROLL") ? atoi(getenv("AMAV_PROJECT_UNROLL")) : 0;
+        const int unroll = env_unroll ? env_unroll : (boxes && C >= 512 ? 8 : 4);
         const size_t lds = (size_t)C * 16 * sizeof(float);
         const dim3 grid(3, F, (RR / 4 + 255) / 256);
         if (unroll == 8)
